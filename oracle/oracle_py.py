@@ -1,0 +1,172 @@
+"""TEST INFRASTRUCTURE — ctypes loader for oracle/libptr_oracle.so (the float64 CPU oracle).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package never does.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libptr_oracle.so")
+
+QUIRK_ROW_SHIFT = 1
+
+
+class Counters(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in
+                ("primary", "hits", "shadow_rays", "exit_tca", "exit_d2", "exit_hit", "light_terms")]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class Hit(C.Structure):
+    _fields_ = [("element", C.c_int32), ("tnear", C.c_double),
+                ("point", C.c_double * 3), ("normal", C.c_double * 3)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        dp = C.POINTER(C.c_double)
+        L.orc_intersect.argtypes = [dp, dp, dp, C.c_double, dp, dp]
+        L.orc_intersect.restype = C.c_int
+        L.orc_trace.argtypes = [dp, C.c_int, dp, dp, dp, dp, C.POINTER(Hit), C.POINTER(Counters)]
+        L.orc_trace.restype = None
+        L.orc_request_pixel.argtypes = [dp, C.c_int, dp, dp, dp]
+        L.orc_request_pixel.restype = None
+        L.orc_render.argtypes = [dp, C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32,
+                                 C.POINTER(C.c_uint32), C.POINTER(Counters)]
+        L.orc_render.restype = None
+        L.orc_render_mt.argtypes = [dp, C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32,
+                                    C.POINTER(C.c_uint32), C.c_int]
+        L.orc_render_mt.restype = None
+        L.orc_render_rgb64.argtypes = [dp, C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, dp]
+        L.orc_render_rgb64.restype = None
+        L.orc_pack.argtypes = [dp]
+        L.orc_pack.restype = C.c_uint32
+        L.orc_reference_angle.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def scene_to_soa(elements):
+    """Serialized spheres (Sphere.serialize wire format, Sphere.js:53-69) -> (12, n) float64 planes
+    in the C-ABI order cx cy cz radius sr sg sb refl transp er eg eb."""
+    n = len(elements)
+    soa = np.zeros((12, n), dtype=np.float64)
+    for i, e in enumerate(elements):
+        m = e["material"]
+        soa[0:3, i] = e["center"]
+        soa[3, i] = e["radius"]
+        soa[4:7, i] = m["surfaceColor"]
+        soa[7, i] = m["reflection"]
+        soa[8, i] = m["transparency"]
+        soa[9:12, i] = m["emissionColor"]
+    return np.ascontiguousarray(soa)
+
+
+def load_scenes(golden_dir):
+    with open(os.path.join(golden_dir, "scenes.json")) as f:
+        return json.load(f)
+
+
+def render(soa, bg, width, height, start_y=0, scan_height=None, flags=QUIRK_ROW_SHIFT,
+           counters=False, threads=1):
+    if scan_height is None:
+        scan_height = height
+    soa = np.ascontiguousarray(soa, dtype=np.float64)
+    n = soa.shape[1]
+    bg = np.ascontiguousarray(bg, dtype=np.float64)
+    out = np.empty(width * scan_height, dtype=np.uint32)
+    outp = out.ctypes.data_as(C.POINTER(C.c_uint32))
+    if threads > 1:
+        lib().orc_render_mt(_dp(soa), n, _dp(bg), width, height, start_y, scan_height, flags, outp, threads)
+        return out
+    cnt = Counters()
+    lib().orc_render(_dp(soa), n, _dp(bg), width, height, start_y, scan_height, flags, outp,
+                     C.byref(cnt) if counters else None)
+    return (out, cnt.as_dict()) if counters else out
+
+
+def render_rgb64(soa, bg, width, height, start_y=0, scan_height=None):
+    if scan_height is None:
+        scan_height = height
+    soa = np.ascontiguousarray(soa, dtype=np.float64)
+    bg = np.ascontiguousarray(bg, dtype=np.float64)
+    out = np.empty((scan_height, width, 3), dtype=np.float64)
+    lib().orc_render_rgb64(_dp(soa), soa.shape[1], _dp(bg), width, height, start_y, scan_height, _dp(out))
+    return out
+
+
+def trace(soa, bg, o, d, want_hit=False):
+    soa = np.ascontiguousarray(soa, dtype=np.float64)
+    bg = np.ascontiguousarray(bg, dtype=np.float64)
+    o = np.ascontiguousarray(o, dtype=np.float64)
+    d = np.ascontiguousarray(d, dtype=np.float64)
+    rgb = np.empty(3, dtype=np.float64)
+    hit = Hit()
+    lib().orc_trace(_dp(soa), soa.shape[1], _dp(bg), _dp(o), _dp(d), _dp(rgb), C.byref(hit), None)
+    if want_hit:
+        return rgb, dict(element=hit.element, tnear=hit.tnear, point=np.array(hit.point[:]),
+                         normal=np.array(hit.normal[:]))
+    return rgb
+
+
+def trace_batch(soa, bg, origins, dirs):
+    """returns (rgb[n,3], element[n], point[n,3], normal[n,3], tnear[n])"""
+    origins = np.ascontiguousarray(origins, dtype=np.float64)
+    dirs = np.ascontiguousarray(dirs, dtype=np.float64)
+    soa = np.ascontiguousarray(soa, dtype=np.float64)
+    bg = np.ascontiguousarray(bg, dtype=np.float64)
+    n = dirs.shape[0]
+    rgb = np.empty((n, 3)); el = np.empty(n, dtype=np.int32)
+    pt = np.empty((n, 3)); nr = np.empty((n, 3)); tn = np.empty(n)
+    hit = Hit()
+    tmp = np.empty(3)
+    L = lib()
+    for k in range(n):
+        L.orc_trace(_dp(soa), soa.shape[1], _dp(bg), _dp(origins[k]), _dp(dirs[k]), _dp(tmp), C.byref(hit), None)
+        rgb[k] = tmp; el[k] = hit.element; pt[k] = hit.point[:]; nr[k] = hit.normal[:]; tn[k] = hit.tnear
+    return rgb, el, pt, nr, tn
+
+
+def request_pixel(soa, bg, d):
+    soa = np.ascontiguousarray(soa, dtype=np.float64)
+    bg = np.ascontiguousarray(bg, dtype=np.float64)
+    d = np.ascontiguousarray(d, dtype=np.float64)
+    rgb = np.empty(3, dtype=np.float64)
+    lib().orc_request_pixel(_dp(soa), soa.shape[1], _dp(bg), _dp(d), _dp(rgb))
+    return rgb
+
+
+def intersect(o, d, c, radius):
+    o = np.ascontiguousarray(o, dtype=np.float64)
+    d = np.ascontiguousarray(d, dtype=np.float64)
+    c = np.ascontiguousarray(c, dtype=np.float64)
+    t0 = C.c_double(1e8); t1 = C.c_double(1e8)
+    hit = lib().orc_intersect(_dp(o), _dp(d), _dp(c), float(radius), C.byref(t0), C.byref(t1))
+    return bool(hit), t0.value, t1.value
+
+
+def pack(rgb):
+    rgb = np.ascontiguousarray(rgb, dtype=np.float64)
+    return int(lib().orc_pack(_dp(rgb)))

@@ -1,0 +1,263 @@
+/*
+ * TEST INFRASTRUCTURE — NOT PART OF THE PRODUCT.  See ptr_oracle.h for scope and pinning.
+ *
+ * Every arithmetic expression below keeps the reference's evaluation order (left to right,
+ * one IEEE-754 double rounding per operation).  Build with -ffp-contract=off: a fused
+ * multiply-add would change low bits and break bit parity with the JavaScript reference.
+ */
+#include "ptr_oracle.h"
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_INFINITY 1e8      /* RayTracer.js:6 — a real far clip, not IEEE infinity */
+#define ORC_BIAS     1e-4     /* RayTracer.js:52 */
+
+/* plane accessors for the 12-plane SoA block */
+#define PL(k) (soa + (size_t)(k) * (size_t)n)
+
+/* ---- JS Math helpers -------------------------------------------------------------------- */
+
+/* Math.min(1, c): NaN if c is NaN (RayTracer.js:179-181) */
+static double js_min1(double c) { return (c != c) ? c : (c < 1.0 ? c : 1.0); }
+
+/* Math.max(0, x): NaN if x is NaN (RayTracer.js:87) */
+static double js_max0(double x) { return (x != x) ? x : (x > 0.0 ? x : 0.0); }
+
+/* Math.round: nearest integer, ties towards +infinity (RayTracer.js:184-186) */
+static double js_round(double x)
+{
+    if (x != x || isinf(x)) return x;
+    double f = floor(x);
+    return (x - f >= 0.5) ? f + 1.0 : f;
+}
+
+/* ECMAScript ToInt32 (operands of << and |, RayTracer.js:188-192) */
+static int32_t js_to_int32(double x)
+{
+    if (x != x || isinf(x)) return 0;
+    double t = trunc(x);
+    double m = fmod(t, 4294967296.0);          /* exact */
+    if (m < 0) m += 4294967296.0;
+    return (int32_t)(uint32_t)m;
+}
+
+uint32_t orc_pack(const double rgb[3])
+{
+    double r = js_round(js_min1(rgb[0]) * 255.0);
+    double g = js_round(js_min1(rgb[1]) * 255.0);
+    double b = js_round(js_min1(rgb[2]) * 255.0);
+    uint32_t v = (uint32_t)(255u << 24)
+               | ((uint32_t)js_to_int32(b) << 16)
+               | ((uint32_t)js_to_int32(g) << 8)
+               | (uint32_t)js_to_int32(r);
+    return v;                                   /* stored through a Uint32Array view */
+}
+
+double orc_reference_angle(void)
+{
+    /* RayTracer.js:152-154: Math.tan(Math.PI * 0.5 * fov / 180), fov = 30 */
+    double fov = 30.0;
+    return tan(3.141592653589793 * 0.5 * fov / 180.0);
+}
+
+/* ---- Vector3.normalize (Vector3.js:23-33): invLen = 1/sqrt(len2), three multiplies ------- */
+static void v_normalize(double v[3])
+{
+    double len2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    if (len2 > 0) {
+        double inv = 1.0 / sqrt(len2);
+        v[0] *= inv; v[1] *= inv; v[2] *= inv;
+    }
+}
+
+/* ---- Sphere.intersect (Sphere.js:15-33) -------------------------------------------------- */
+static inline int intersect_r2(const double o[3], const double d[3],
+                               double cx, double cy, double cz, double radius2,
+                               double *t0, double *t1, orc_counters *cnt)
+{
+    double lx = cx - o[0], ly = cy - o[1], lz = cz - o[2];
+    double tca = lx * d[0] + ly * d[1] + lz * d[2];
+    if (tca < 0) { if (cnt) cnt->exit_tca++; return 0; }
+    double d2 = (lx * lx + ly * ly + lz * lz) - tca * tca;
+    if (d2 > radius2) { if (cnt) cnt->exit_d2++; return 0; }
+    double thc = sqrt(radius2 - d2);
+    *t0 = tca - thc;
+    *t1 = tca + thc;
+    if (cnt) cnt->exit_hit++;
+    return 1;
+}
+
+int orc_intersect(const double o[3], const double d[3], const double c[3], double radius,
+                  double *t0, double *t1)
+{
+    return intersect_r2(o, d, c[0], c[1], c[2], radius * radius /* Sphere.js:11 */, t0, t1, 0);
+}
+
+/* ---- RayTracer.trace (RayTracer.js:18-95) ------------------------------------------------ */
+void orc_trace(const double *soa, int n, const double bg[3],
+               const double o[3], const double d[3], double rgb[3],
+               orc_hit *hit, orc_counters *cnt)
+{
+    const double *cx = PL(0), *cy = PL(1), *cz = PL(2), *rad = PL(3);
+    const double *sr = PL(4), *sg = PL(5), *sb = PL(6);
+    const double *er = PL(9), *eg = PL(10), *eb = PL(11);
+
+    if (cnt) cnt->primary++;
+
+    /* nearest hit, scene order, strict '<' so the first element wins ties (:26-41) */
+    double tnear = ORC_INFINITY;
+    int element = -1;
+    for (int i = 0; i < n; i++) {
+        double t0 = ORC_INFINITY, t1 = ORC_INFINITY;
+        if (intersect_r2(o, d, cx[i], cy[i], cz[i], rad[i] * rad[i], &t0, &t1, cnt)) {
+            if (t0 < 0) t0 = t1;
+            if (t0 < tnear) { tnear = t0; element = i; }
+        }
+    }
+    if (hit) { hit->element = element; hit->tnear = tnear; }
+    if (element < 0) {                       /* :43-46 */
+        rgb[0] = bg[0]; rgb[1] = bg[1]; rgb[2] = bg[2];
+        if (hit) memset(hit->point, 0, sizeof hit->point), memset(hit->normal, 0, sizeof hit->normal);
+        return;
+    }
+    if (cnt) cnt->hits++;
+
+    /* hit frame (:48-58) */
+    double P[3] = { o[0] + d[0] * tnear, o[1] + d[1] * tnear, o[2] + d[2] * tnear };
+    double N[3] = { P[0] - cx[element], P[1] - cy[element], P[2] - cz[element] };   /* Sphere.js:47-51 */
+    v_normalize(N);
+    if (d[0] * N[0] + d[1] * N[1] + d[2] * N[2] > 0) { N[0] = -N[0]; N[1] = -N[1]; N[2] = -N[2]; }
+    if (hit) { memcpy(hit->point, P, sizeof P); memcpy(hit->normal, N, sizeof N); }
+
+    /* direct lighting from every emissive element, binary shadow term (:60-91) */
+    double acc[3] = { 0, 0, 0 };
+    for (int i = 0; i < n; i++) {
+        if (er[i] > 0 || eg[i] > 0 || eb[i] > 0) {
+            if (cnt) { cnt->shadow_rays++; cnt->light_terms++; }
+            double tr = 1.0;
+            double L[3] = { cx[i] - P[0], cy[i] - P[1], cz[i] - P[2] };
+            v_normalize(L);
+            for (int j = 0; j < n; j++) {
+                if (i != j) {
+                    /* origin recomputed per j in the reference; same value every time (:77) */
+                    double so[3] = { P[0] + N[0] * ORC_BIAS, P[1] + N[1] * ORC_BIAS, P[2] + N[2] * ORC_BIAS };
+                    double t0, t1;
+                    if (intersect_r2(so, L, cx[j], cy[j], cz[j], rad[j] * rad[j], &t0, &t1, cnt)) {
+                        tr = 0.0;             /* any hit blocks, distance ignored (F7) */
+                        break;
+                    }
+                }
+            }
+            double ratio = js_max0(N[0] * L[0] + N[1] * L[1] + N[2] * L[2]);
+            /* surfaceColor.clone().product(transmission).product(emission.clone().multiply(ratio)) (:89) */
+            acc[0] += (sr[element] * tr) * (er[i] * ratio);
+            acc[1] += (sg[element] * tr) * (eg[i] * ratio);
+            acc[2] += (sb[element] * tr) * (eb[i] * ratio);
+        }
+    }
+    acc[0] += er[element]; acc[1] += eg[element]; acc[2] += eb[element];     /* :93 */
+    rgb[0] = acc[0]; rgb[1] = acc[1]; rgb[2] = acc[2];
+}
+
+/* ---- RayTracer.requestPixel (RayTracer.js:98-115) ---------------------------------------- */
+void orc_request_pixel(const double *soa, int n, const double bg[3], const double d[3], double rgb[3])
+{
+    const double o[3] = { 0, 0, 0 };
+    double c[3];
+    orc_trace(soa, n, bg, o, d, c, 0, 0);
+    rgb[0] = js_round(js_min1(c[0]) * 255.0);
+    rgb[1] = js_round(js_min1(c[1]) * 255.0);
+    rgb[2] = js_round(js_min1(c[2]) * 255.0);
+}
+
+/* ---- RayTracer.render (RayTracer.js:132-197) --------------------------------------------- */
+static void primary_dir(int x, int y, double invW, double invH, double angle, double aspect, double dir[3])
+{
+    /* :171-174 */
+    double xx = (2 * ((x + 0.5) * invW) - 1) * angle * aspect;
+    double yy = (1 - 2 * ((y + 0.5) * invH)) * angle;
+    dir[0] = xx; dir[1] = yy; dir[2] = -1;
+    v_normalize(dir);
+}
+
+static void render_rows(const double *soa, int n, const double bg[3],
+                        int width, int height, int start_y, int scan_height,
+                        uint32_t flags, uint32_t *out, orc_counters *cnt,
+                        int row_first, int row_step)
+{
+    const double invW = 1.0 / width, invH = 1.0 / height;
+    const double aspect = (double)width / (double)height;
+    const double angle = orc_reference_angle();
+    const double origin[3] = { 0, 0, 0 };
+    for (int y = start_y + row_first; y < start_y + scan_height; y += row_step) {
+        for (int x = 0; x < width; x++) {
+            long long idx;
+            if (flags & ORC_QUIRK_ROW_SHIFT)
+                idx = (long long)width * (y - start_y) - (width - x);   /* :169 */
+            else
+                idx = (long long)width * (y - start_y) + x;
+            double dir[3], c[3];
+            primary_dir(x, y, invW, invH, angle, aspect, dir);
+            orc_trace(soa, n, bg, origin, dir, c, 0, cnt);
+            if (idx >= 0)                      /* negative typed-array index: silently dropped */
+                out[idx] = orc_pack(c);
+        }
+    }
+}
+
+void orc_render(const double *soa, int n, const double bg[3],
+                int width, int height, int start_y, int scan_height,
+                uint32_t flags, uint32_t *out, orc_counters *cnt)
+{
+    memset(out, 0, (size_t)width * (size_t)scan_height * 4);   /* fresh ArrayBuffer (:148) */
+    render_rows(soa, n, bg, width, height, start_y, scan_height, flags, out, cnt, 0, 1);
+}
+
+typedef struct {
+    const double *soa; int n; const double *bg;
+    int width, height, start_y, scan_height; uint32_t flags; uint32_t *out;
+    int first, step;
+} mt_job;
+
+static void *mt_main(void *p)
+{
+    mt_job *j = (mt_job *)p;
+    render_rows(j->soa, j->n, j->bg, j->width, j->height, j->start_y, j->scan_height,
+                j->flags, j->out, 0, j->first, j->step);
+    return 0;
+}
+
+void orc_render_mt(const double *soa, int n, const double bg[3],
+                   int width, int height, int start_y, int scan_height,
+                   uint32_t flags, uint32_t *out, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    memset(out, 0, (size_t)width * (size_t)scan_height * 4);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    mt_job *jobs = (mt_job *)malloc(sizeof(mt_job) * (size_t)nthreads);
+    for (int t = 0; t < nthreads; t++) {
+        mt_job j = { soa, n, bg, width, height, start_y, scan_height, flags, out, t, nthreads };
+        jobs[t] = j;
+        pthread_create(&th[t], 0, mt_main, &jobs[t]);
+    }
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], 0);
+    free(th); free(jobs);
+}
+
+void orc_render_rgb64(const double *soa, int n, const double bg[3],
+                      int width, int height, int start_y, int scan_height, double *out_rgb)
+{
+    const double invW = 1.0 / width, invH = 1.0 / height;
+    const double aspect = (double)width / (double)height;
+    const double angle = orc_reference_angle();
+    const double origin[3] = { 0, 0, 0 };
+    for (int y = start_y; y < start_y + scan_height; y++)
+        for (int x = 0; x < width; x++) {
+            double dir[3];
+            primary_dir(x, y, invW, invH, angle, aspect, dir);
+            orc_trace(soa, n, bg, origin, dir,
+                      out_rgb + 3 * ((size_t)width * (size_t)(y - start_y) + (size_t)x), 0, 0);
+        }
+}
