@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the per-pixel hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path (camera ray -> nearest hit -> shadowed Lambert -> RGBA8 pack,
+RT/src/RayTracer.js:163-193) over one batch: FRAMES frames of the reference's example scene
+(RT/examples/example1.js:9-45) at 1920x1080, 1 sample per pixel, reference semantics (the reference
+has no bounce loop), in HYBRID precision mode whose output bytes equal the reference's.
+Scene blocks are resident in HBM before the timed region and the frames stay in HBM.
+
+N > 1: every frame is split into cyclic strips of 8 scanlines over the ranks (the reference's
+RenderPlanner band split, RT/src/RenderPlanner.js:75-76, made cyclic for load balance); every
+step ends with the gather of all strips to rank 0 over RCCL (torch.distributed "nccl") and the
+re-interleave there, inside the timed region.  Weak scaling: each rank renders FRAMES * N frames'
+worth of its strips, i.e. per-GPU work is fixed as N grows.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd", "py"))
+
+WIDTH, HEIGHT = 1920, 1080
+FRAMES_PER_GPU = 64
+STRIP = 8
+PEAK_FP32_VALU_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
+PEAK_HBM_GBPS = 8000.0
+
+
+def example1_soa():
+    """RT/examples/example1.js:9-45 as the 12-plane SoA of include/ptr.h."""
+    rows = [  # cx, cy, cz, radius, sr, sg, sb, refl, transp, er, eg, eb
+        (0.0, -10004, -20, 10000, 0.2, 0.2, 0.2, 0, 0, 0, 0, 0),
+        (0, 0, -20, 4, 1.00, 0.32, 0.36, 1, 0.5, 0, 0, 0),
+        (5, -1, -15, 2, 0.9, 0.76, 0.46, 1, 0, 0, 0, 0),
+        (5, 0, -25, 3, 0.65, 0.77, 0.97, 1, 0, 0, 0, 0),
+        (-5.5, 0, -15, 3, 0.9, 0.9, 0.9, 1, 0, 0, 0, 0),
+        (0, 20, -30, 3, 0, 0, 0, 0, 0, 1.2, 1.2, 1.2),
+        (0, 10, 10, 3, 0, 0, 0, 0, 0, 1, 1, 1),
+    ]
+    return np.ascontiguousarray(np.array(rows, dtype=np.float64).T)
+
+
+def algorithmic_flops(st):
+    """30 P + 8 A + 15 B + 19 C + 33 H + 31 (hit, light) pairs."""
+    return (30 * st["primary"] + 8 * st["exit_tca"] + 15 * st["exit_d2"] + 19 * st["exit_hit"]
+            + 33 * st["hits"] + 31 * st["shadow_rays"])
+
+
+def cpu_baseline(soa, bg, seconds=12.0):
+    """The CPU oracle (float64 C restatement of the reference) on this host's cores, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as orc                      # checker / baseline only, never the product path
+    threads = max(1, min(16, os.cpu_count() or 1))
+    orc.render(soa, bg, 320, 180, flags=0, threads=threads)          # warm up, page in
+    _, cnt = orc.render(soa, bg, WIDTH, HEIGHT, flags=0, counters=True)
+    rays = cnt["primary"] + cnt["shadow_rays"]
+    t0 = time.perf_counter()
+    frames = 0
+    while True:
+        orc.render(soa, bg, WIDTH, HEIGHT, flags=0, threads=threads)
+        frames += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            break
+    return {"value": round(rays * frames / dt / 1e6, 2), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{frames} frames of the example scene at {WIDTH}x{HEIGHT} in {dt:.1f} s, "
+                      f"oracle/ptr_oracle.c (float64 C port of the reference) on {threads} pthreads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import ptr_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    soa = example1_soa()
+    bg = np.array([2.0, 2.0, 2.0])
+    frames_total = args.frames * world            # weak scaling: fixed per-GPU work
+    rdr = ptr_amd.Renderer(local_rank)
+    rdr.set_scene(np.ascontiguousarray(np.broadcast_to(soa, (frames_total,) + soa.shape)))
+    rdr.set_background(bg)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # ---- per-frame work counts from the GPU's own counting kernel (outside the timed region)
+    one = torch.empty(WIDTH * HEIGHT, dtype=torch.int32, device="cuda")
+    p_stats = rdr.params(WIDTH, HEIGHT, flags=ptr_amd.FLAG_STATS)
+    rdr.render_device(p_stats, 0, 1, one.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    st = rdr.stats()
+    rays_per_frame = st["primary"] + st["shadow_rays"]
+    flops_per_frame = algorithmic_flops(st)
+
+    # ---- this rank's share: cyclic strips of STRIP rows (all rows when world == 1)
+    if world == 1:
+        local_rows = HEIGHT
+        part = ptr_amd.StripPart(1, 0, HEIGHT)
+    else:
+        part = ptr_amd.StripPart(world, rank, STRIP)
+        local_rows = part.local_rows(HEIGHT)
+    max_rows = ptr_amd.StripPart(world, 0, STRIP).local_rows(HEIGHT) if world > 1 else HEIGHT
+    local = torch.empty((frames_total, max_rows, WIDTH), dtype=torch.int32, device="cuda")
+    p = rdr.params(WIDTH, HEIGHT, 0, local_rows, flags=0)
+    gathered = full = row_index = None
+    if world > 1 and rank == 0:
+        gathered = [torch.empty_like(local) for _ in range(world)]
+        full = torch.empty((frames_total, HEIGHT, WIDTH), dtype=torch.int32, device="cuda")
+        row_index = [torch.as_tensor(ptr_amd.StripPart(world, r, STRIP).global_rows(HEIGHT), device="cuda")
+                     for r in range(world)]
+
+    def step(flags=0):
+        p.flags = flags
+        rdr.render_strips_device(p, part, 0, frames_total, local.data_ptr(), stream=stream,
+                                 frame_stride_px=max_rows * WIDTH)
+        if world > 1:
+            dist.gather(local, gathered, dst=0)
+            if rank == 0:
+                for r in range(world):
+                    full.index_copy_(1, row_index[r], gathered[r][:, : row_index[r].numel(), :])
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- dominant kernel's own duration: HIP events on the launch stream, live, same workload
+    kms = []
+    for _ in range(min(args.steps, 10)):
+        step(ptr_amd.FLAG_TIMING)
+        kms.append(rdr.kernel_ms())
+    fence()
+    main_ms = float(np.mean([k[0] for k in kms]))
+    retrace_ms = float(np.mean([k[1] for k in kms]))
+
+    if rank == 0:
+        share = local_rows / HEIGHT                      # fraction of every frame this rank renders
+        total_rays = rays_per_frame * frames_total       # all ranks together, per step
+        value = total_rays * args.steps / elapsed / 1e6
+        launch_flops = flops_per_frame * frames_total * share
+        launch_bytes = 4.0 * WIDTH * local_rows * frames_total
+        achieved = launch_flops / (main_ms * 1e-3) / 1e12
+        out = {
+            "metric": "Mrays/sec (primary+secondary) at 1080p",
+            "value": round(value, 1), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (uncertain pixels re-traced in f64; output bytes equal the f64 reference)",
+            "data": "synthetic",
+            "config": {"workload": f"example1 scene (7 spheres, 2 lights) {WIDTH}x{HEIGHT}, 1 spp, reference "
+                                   f"semantics (depth 0), {args.frames} frames per GPU per step, hybrid mode",
+                       "frames_per_step": frames_total, "rays_per_frame": rays_per_frame,
+                       "parallelism": "1 GPU" if world == 1 else
+                       f"{world} ranks, cyclic {STRIP}-row strips, RCCL gather to rank 0 in the timed region"},
+            "Mpixels_per_s": round(WIDTH * HEIGHT * frames_total * args.steps / elapsed / 1e6, 1),
+            "roofline": {"bound": "valu", "kernel": "render_fast_kernel<hybrid>",
+                         "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": None,
+                         "kernel_ms": round(main_ms, 4), "retrace_kernel_ms": round(retrace_ms, 4),
+                         "algorithmic_flops_per_launch": int(launch_flops),
+                         "hbm_frac": round(launch_bytes / (main_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                         "note": "FP32 vector-ALU bound (SURVEY.md 8d): no dense contraction, 4 B/pixel of HBM "
+                                 "traffic; achieved = algorithmic FLOPs of the reference's control flow"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(soa, bg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,209 @@
+/*
+ * ptr.h — C ABI of the MI355X-native per-pixel path of raytracer-js ("path-tracer").
+ *
+ * This is the whole drop-in boundary: plain pointers and sizes, `int` status codes, no C++
+ * or torch types.  The Node N-API addon (path-tracer_amd/js/addon/ptr_napi.c), the Python
+ * ctypes binding used by tests/bench (path-tracer_amd/py/ptr_amd) and any other host bind to
+ * exactly these symbols.  Each entry point cites the reference interface it replaces
+ * (paths relative to the reference repo, RT/ = raytracer-js-master/).
+ *
+ * The reference has no FFI of its own; the boundary is its JavaScript class API
+ * (SURVEY.md §8b).  The JS classes in path-tracer_amd/js/src keep that API and call down here.
+ *
+ * Threading: calls on one ptr_ctx are serialised by the library (internal mutex); different
+ * contexts may be used from different threads.  No C++ exception crosses this boundary.
+ * All device memory is owned by the library; host buffers are owned by the caller.
+ */
+#ifndef PTR_H
+#define PTR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTR_ABI_VERSION 1
+
+/* ---- status codes (0 ok, <0 error; text via ptr_last_error) ---------------------------- */
+#define PTR_OK               0
+#define PTR_ERR_INVALID     -1   /* bad argument (null pointer, non-positive size, overflow)   */
+#define PTR_ERR_NO_DEVICE   -2   /* no usable gfx950 device / HIP runtime failure at create    */
+#define PTR_ERR_HIP         -3   /* a HIP call failed; message carries hipGetErrorString       */
+#define PTR_ERR_NO_SCENE    -4   /* render/trace before ptr_set_scene*                         */
+#define PTR_ERR_UNSUPPORTED -5   /* feature bit not built into this library version            */
+
+/* ---- ptr_params.flags ------------------------------------------------------------------- */
+/* Reproduce RT/src/RayTracer.js:169 exactly: row y is stored at row (y-start_y-1), the band's
+ * first row is dropped and its last stored row stays 0x00000000.  The drop-in
+ * RayTracer.render() sets it; renderFrame()/benchmarks do not. */
+#define PTR_QUIRK_ROW_SHIFT   0x0001u
+/* Precision mode (at most one).  Default (neither bit): HYBRID — every pixel is traced in
+ * float32 with conservative uncertainty tests; pixels whose hit/miss, ordering, shadow or
+ * 8-bit rounding decision is not certain are queued and re-traced by the float64 kernel,
+ * which follows the reference operation for operation.  Output target: identical bytes.   */
+#define PTR_MODE_EXACT_F64    0x0002u  /* whole band in float64, op-for-op the reference      */
+#define PTR_MODE_F32_ONLY     0x0004u  /* float32 only, no re-trace (tolerance mode)          */
+/* Accumulate work counters (ptr_get_stats) during this call; slower, not for timing.        */
+#define PTR_FLAG_STATS        0x0008u
+/* Bracket this call's kernels with HIP events on the launch stream (ptr_get_kernel_ms).        */
+#define PTR_FLAG_TIMING       0x0010u
+/* Diagnostics, with PTR_MODE_F32_ONLY: out_rgba8 receives, instead of a colour, the bit mask of
+ * the reasons the hybrid mode would re-trace the pixel (1 hit/miss band, 2 origin on a surface,
+ * 4 nearest-vs-second ordering, 8 far clip, 16 shadow band, 32 rounding band).               */
+#define PTR_DEBUG_REASONS     0x8000u
+
+typedef struct ptr_ctx ptr_ctx;
+
+/* Replaces the argument list of RayTracer.render(width,height,startY,scanHeight,isFirstFrame)
+ * (RT/src/RayTracer.js:132).  isFirstFrame is unused by the reference and has no field.
+ * max_depth/spp/seed belong to the extension modes (reflection bounces / stochastic sampling,
+ * which the reference does not implement — SURVEY.md F1,F3); they must be 0/1/any here.     */
+typedef struct ptr_params {
+    int32_t  width;        /* full image width  (RayTracer.js:150,153)                        */
+    int32_t  height;       /* full image height (RayTracer.js:151,153)                        */
+    int32_t  start_y;      /* first scanline of the band (RayTracer.js:134-136), default 0    */
+    int32_t  scan_height;  /* rows in the band (RayTracer.js:138-140), default = height       */
+    int32_t  max_depth;    /* 0 = reference semantics (no bounce exists in the reference)     */
+    int32_t  spp;          /* 1                                                               */
+    uint32_t seed;         /* unused at spp = 1                                               */
+    uint32_t flags;        /* PTR_QUIRK_* | PTR_MODE_* | PTR_FLAG_*                           */
+} ptr_params;
+
+/* Camera.  The reference hot path ignores the user's Camera object and hard-codes origin 0,
+ * fov 30 degrees, looking down -Z (RT/src/RayTracer.js:150-155,171-174); that is
+ * the default.  dir = normalize(xx*right + yy*up + forward) with xx,yy as RayTracer.js:171-172.
+ * tan_half_fov is the reference's `angle` (= Math.tan(Math.PI*0.5*fov/180)), computed by the
+ * host language so that its libm decides the bits, exactly as in the reference.            */
+typedef struct ptr_camera {
+    double origin[3];
+    double right[3];
+    double up[3];
+    double forward[3];
+    double tan_half_fov;
+} ptr_camera;
+
+/* Work counters of the last call that had PTR_FLAG_STATS set.  Same counting rule as the
+ * algorithmic-FLOP model of SURVEY.md §8(d).                                                */
+typedef struct ptr_stats {
+    uint64_t primary;       /* primary rays traced                                            */
+    uint64_t hits;          /* primary rays that hit an element                               */
+    uint64_t shadow_rays;   /* one per (hit pixel, emissive element)                          */
+    uint64_t exit_tca;      /* Sphere.intersect calls leaving at tca<0   (RT/src/Sphere.js:18) */
+    uint64_t exit_d2;       /* ... at d2>radius2                          (RT/src/Sphere.js:23) */
+    uint64_t exit_hit;      /* ... returning true                         (RT/src/Sphere.js:32) */
+    uint64_t retraced;      /* hybrid mode: pixels re-traced in float64 (last call, always set) */
+} ptr_stats;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+
+/* Replaces `new RayTracer(backgroundColor, scene[, camera])` (RT/src/RayTracer.js:12-16) as the
+ * owner of per-renderer state.  device = HIP device ordinal.  Fails (PTR_ERR_NO_DEVICE) when no
+ * GPU is present: there is no CPU fallback.                                                  */
+int  ptr_create(int device, ptr_ctx **out);
+void ptr_destroy(ptr_ctx *ctx);
+
+/* Text of the last error on ctx (or, with ctx == NULL, of the calling thread's last failed
+ * ptr_create).  Never NULL.                                                                   */
+const char *ptr_last_error(ptr_ctx *ctx);
+
+int ptr_abi_version(void);
+
+/* ---- scene upload ------------------------------------------------------------------------ */
+
+/* Replaces Scene.add()/getElements() + Sphere/Material field reads done by trace()
+ * (RT/src/Scene.js:9-15, RT/src/RayTracer.js:22,29,60-66) and the worker wire format
+ * (RT/src/Sphere.js:53-83, RT/src/RenderWorker.js:27-33).
+ * soa = 12 planes of n values, in the order
+ *     cx cy cz radius   sr sg sb   reflection transparency   er eg eb
+ * scene order preserved (it decides ties and the shadow loop's first blocker).  radius2 and the
+ * light list are derived natively.  The library copies; it keeps no reference to soa.
+ * n == 0 is allowed (every pixel is background).
+ * JavaScript numbers are float64, so the _f64 form is the one the drop-in classes use; the
+ * float form promotes each value to double first.                                            */
+int ptr_set_scene(ptr_ctx *ctx, const float *soa, int n_spheres);
+int ptr_set_scene_f64(ptr_ctx *ctx, const double *soa, int n_spheres);
+
+/* A sequence of n_frames scenes with the same sphere count (animation loops of
+ * RT/examples/example2.js:98-113 and example3.js:89-98 re-render the scene with moved centres).
+ * soa = n_frames consecutive 12-plane blocks.  ptr_set_scene* is the n_frames == 1 case.      */
+int ptr_set_scene_sequence_f64(ptr_ctx *ctx, const double *soa, int n_spheres, int n_frames);
+
+/* Replaces the backgroundColor constructor argument (RT/src/RayTracer.js:13, returned on a miss
+ * at :43-46).  Unclamped value; the pack clamps.                                             */
+int ptr_set_background(ptr_ctx *ctx, const float rgb[3]);
+int ptr_set_background_f64(ptr_ctx *ctx, const double rgb[3]);
+
+/* cam == NULL restores the reference's fixed camera (RT/src/RayTracer.js:150-155).            */
+int ptr_set_camera(ptr_ctx *ctx, const ptr_camera *cam);
+
+/* ---- render ------------------------------------------------------------------------------ */
+
+/* Replaces RayTracer.render() (RT/src/RayTracer.js:132-197): ray generation, trace, clamp,
+ * RGBA8 pack over the band [start_y, start_y+scan_height).  Synchronous.
+ * out_rgba8: caller-allocated HOST buffer of width*scan_height uint32 (A<<24|B<<16|G<<8|R),
+ * fully written.  out_rgba32f (nullable): HOST buffer of width*scan_height*4 floats receiving
+ * the unclamped trace colour (r,g,b,1), never row-shifted.  Renders frame 0 of a sequence.    */
+int ptr_render(ptr_ctx *ctx, const ptr_params *p, uint32_t *out_rgba8, float *out_rgba32f);
+
+/* Same work, but outputs are DEVICE pointers (e.g. a torch tensor's data_ptr) and the call only
+ * enqueues on `stream` (a hipStream_t, NULL = the context's own stream) without synchronising.
+ * Renders frames [first_frame, first_frame+n_frames) of the uploaded sequence back to back into
+ * d_rgba8 (n_frames * width * scan_height uint32) with one launch per kernel.
+ * This is the entry bench.py times: inputs resident in HBM, outputs left in HBM.              */
+int ptr_render_device(ptr_ctx *ctx, const ptr_params *p, int first_frame, int n_frames,
+                      void *d_rgba8, void *d_rgba32f /* nullable */, void *stream);
+
+/* Cyclic-strip form of the reference's band split (RT/src/RenderPlanner.js:75-76 gives worker i
+ * the contiguous band [i*floor(h/n), (i+1)*floor(h/n)); the example frame is ~3x costlier at the
+ * bottom than at the top, so for multi-GPU balance the rows are dealt out in strips instead).
+ * The image rows are cut into strips of strip_height rows; strip k belongs to part k % n_parts.
+ * This call renders the rows of `part`, in increasing y, compactly: p->scan_height must be the
+ * number of such rows (ptr_strip_rows), p->start_y must be 0, PTR_QUIRK_ROW_SHIFT is not allowed.
+ * frame_stride_px = distance in pixels between consecutive frames in the outputs
+ * (0 = width*scan_height), so that equally sized buffers can be gathered across ranks.          */
+typedef struct ptr_strips {
+    int32_t n_parts;       /* >= 1 (1 = the whole image)                                       */
+    int32_t part;          /* 0 .. n_parts-1                                                   */
+    int32_t strip_height;  /* >= 1                                                             */
+    int32_t reserved;      /* 0                                                                */
+} ptr_strips;
+int ptr_strip_rows(const ptr_strips *s, int height);
+int ptr_render_strips_device(ptr_ctx *ctx, const ptr_params *p, const ptr_strips *s,
+                             int first_frame, int n_frames, void *d_rgba8, void *d_rgba32f,
+                             uint64_t frame_stride_px, void *stream);
+
+/* Block until everything enqueued on the context's own stream has finished.                   */
+int ptr_sync(ptr_ctx *ctx);
+
+/* ---- single rays ------------------------------------------------------------------------- */
+
+/* Batched RayTracer.requestPixel(rayDir) (RT/src/RayTracer.js:98-115): origin = camera origin,
+ * out_rgb = 3 bytes per ray (Math.round(min(1,c)*255) & 0xff).  out_hit_xyz / out_normal_xyz
+ * (nullable, 3 floats per ray) receive the hit point and shading normal, zeros on a miss —
+ * what the render cache's Sample needs (rendercache-js/src/Sample.js:49-75).                   */
+int ptr_trace_batch(ptr_ctx *ctx, const float *dirs_xyz, int n,
+                    uint8_t *out_rgb, float *out_hit_xyz, float *out_normal_xyz);
+
+/* Batched RayTracer.trace(rayOrigin, rayDir, depth) (RT/src/RayTracer.js:18-95) in float64,
+ * op-for-op: out_rgb64 = unclamped colour (3 doubles per ray).  origins == NULL means the
+ * camera origin for every ray.  out_element (nullable) = index of the hit element or -1;
+ * out_hit_xyz / out_normal_xyz (nullable) as above but double.  All HOST pointers.           */
+int ptr_trace_batch_f64(ptr_ctx *ctx, const double *origins_xyz, const double *dirs_xyz, int n,
+                        double *out_rgb64, int32_t *out_element,
+                        double *out_hit_xyz, double *out_normal_xyz);
+
+/* ---- introspection ----------------------------------------------------------------------- */
+int ptr_get_stats(ptr_ctx *ctx, ptr_stats *out);
+
+/* Device time of the kernels of the last call that had PTR_FLAG_TIMING set, from HIP events
+ * recorded on the stream the kernels were launched on: main_ms = the per-pixel kernel
+ * (float32 kernel in hybrid / f32-only mode, float64 kernel in exact mode), retrace_ms = the
+ * float64 re-trace of queued pixels (0 outside hybrid mode).  Waits for those kernels.        */
+int ptr_get_kernel_ms(ptr_ctx *ctx, float *main_ms, float *retrace_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTR_H */

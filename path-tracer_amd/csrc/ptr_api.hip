@@ -1,0 +1,666 @@
+// ptr_api.hip — host side of the C ABI declared in include/ptr.h.
+//
+// Owns all device memory of a renderer context: the frame blocks (scene sequence flattened to
+// the layouts of ptr_device.h), the re-trace queue and its two counter words, the stats words
+// and staging buffers for the host-pointer entry points.  There is no CPU implementation of
+// the path in here: without a GPU ptr_create fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/ptr.h"
+#include "ptr_device.h"
+#include "ptr_kernels.h"
+
+using namespace ptr;
+
+namespace {
+
+thread_local std::string g_create_error = "";
+
+struct DeviceBuffer {
+    void*  ptr = nullptr;
+    size_t bytes = 0;
+};
+
+// layout of ptr_ctx::words (device): two queue counters on lines of their own, then the stats
+constexpr size_t WORDS_COUNTER_A = 0;
+constexpr size_t WORDS_COUNTER_B = 256;
+constexpr size_t WORDS_STATS     = 512;     // 8 x uint64
+constexpr size_t WORDS_BYTES     = 768;
+
+}  // namespace
+
+struct ptr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::string err;
+
+    // host copy of the scene sequence (float64, C-ABI plane order)
+    std::vector<double> soa;
+    int n_spheres = 0;
+    int n_frames = 0;
+    bool have_scene = false;
+    double bg[3] = {0, 0, 0};
+    ptr_camera cam;
+    bool cam_general = false;
+    bool dirty = true;                 // frame blocks need a rebuild + upload
+    bool needs_exact = false;          // some frame holds values the float32 path cannot take
+
+    DeviceBuffer scenes;               // n_frames frame blocks
+    size_t frame_stride = 0;
+    DeviceBuffer queue;                // uint32 per pixel of the largest hybrid call so far
+    DeviceBuffer words;                // see WORDS_*
+    unsigned hybrid_calls = 0;         // picks the counter word of the next hybrid call
+    bool words_dirty = true;           // counters/stats must be zeroed before the next use
+    DeviceBuffer out8, out32f;         // staging for ptr_render
+    DeviceBuffer tr_in_o, tr_in_d, tr_rgb, tr_el, tr_hit, tr_nrm;   // staging for ptr_trace_batch*
+    std::vector<unsigned char> host_blocks;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // PTR_FLAG_TIMING
+    int timed_kernels = 0;             // kernels bracketed by ev[] in the last timed call
+};
+
+namespace {
+
+int fail(ptr_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(c, call)                                                                      \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail((c), PTR_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));     \
+    } while (0)
+
+#define PTR_TRY(expr)                                                                         \
+    do { int rc_ = (expr); if (rc_ != PTR_OK) return rc_; } while (0)
+
+int grow(ptr_ctx* c, DeviceBuffer& b, size_t bytes)
+{
+    if (bytes <= b.bytes) return PTR_OK;
+    if (b.ptr) { HIP_TRY(c, hipFree(b.ptr)); b.ptr = nullptr; b.bytes = 0; }
+    HIP_TRY(c, hipMalloc(&b.ptr, bytes));
+    b.bytes = bytes;
+    return PTR_OK;
+}
+
+void default_camera(ptr_camera& cam)
+{
+    // RT/src/RayTracer.js:150-155,171-174: origin 0, fov 30, looking down -Z
+    std::memset(&cam, 0, sizeof cam);
+    cam.right[0] = 1.0; cam.up[1] = 1.0; cam.forward[2] = -1.0;
+    cam.tan_half_fov = std::tan(3.141592653589793 * 0.5 * 30.0 / 180.0);
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct BlockLayout {
+    uint32_t off_g64, off_m64, off_p32, off_m32, off_lights;
+    size_t   bytes;
+};
+
+BlockLayout block_layout(int n)
+{
+    BlockLayout L;
+    size_t o = sizeof(FrameHeader);
+    L.off_g64 = (uint32_t)o;    o += align_up(sizeof(SphereG64) * (size_t)n, 16);
+    L.off_m64 = (uint32_t)o;    o += align_up(sizeof(SphereM64) * (size_t)n, 16);
+    L.off_p32 = (uint32_t)o;    o += align_up(sizeof(SphereP32) * (size_t)n, 16);
+    L.off_m32 = (uint32_t)o;    o += align_up(sizeof(SphereM32) * (size_t)n, 16);
+    L.off_lights = (uint32_t)o; o += align_up(sizeof(int32_t) * (size_t)(n > 0 ? n : 1), 16);
+    L.bytes = align_up(o, 256);
+    return L;
+}
+
+// error bounds of the float32 primary test (see SphereP32); EPS32 = 2^-24
+constexpr double EPS32   = 5.9604644775390625e-08;
+constexpr double PR_RELD = 24.0 * EPS32;   // disc = b^2 - cc:  |err| <= PR_RELD * scale
+constexpr double PR_RELB = 10.0 * EPS32;   // b = l.d:          |err| <= PR_RELB * sqrt(scale)
+
+// Flatten one scene (12 planes of n doubles) into a frame block.  Returns needs_exact.
+bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* soa, int n,
+                       const double bg[3], const double org[3])
+{
+    std::memset(dst, 0, L.bytes);
+    FrameHeader* h = reinterpret_cast<FrameHeader*>(dst);
+    SphereG64* g64 = reinterpret_cast<SphereG64*>(dst + L.off_g64);
+    SphereM64* m64 = reinterpret_cast<SphereM64*>(dst + L.off_m64);
+    SphereP32* p32 = reinterpret_cast<SphereP32*>(dst + L.off_p32);
+    SphereM32* m32 = reinterpret_cast<SphereM32*>(dst + L.off_m32);
+    int32_t* lights = reinterpret_cast<int32_t*>(dst + L.off_lights);
+    auto pl = [&](int k, int i) { return soa[(size_t)k * (size_t)n + (size_t)i]; };
+
+    bool needs_exact = false;
+    int nl = 0;
+    for (int i = 0; i < n; i++) {
+        const double cx = pl(0, i), cy = pl(1, i), cz = pl(2, i), r = pl(3, i);
+        const double sr = pl(4, i), sg = pl(5, i), sb = pl(6, i);
+        const double er = pl(9, i), eg = pl(10, i), eb = pl(11, i);
+        for (double v : {cx, cy, cz, r, sr, sg, sb, er, eg, eb})
+            if (!(std::fabs(v) <= 1e15)) needs_exact = true;          // NaN, Inf, huge
+        if (sr < 0 || sg < 0 || sb < 0 || er < 0 || eg < 0 || eb < 0) needs_exact = true;
+
+        g64[i] = SphereG64{cx, cy, cz, r * r};          // radius2 = radius*radius, Sphere.js:11
+        m64[i] = SphereM64{sr, sg, sb, er, eg, eb};
+        if (er > 0 || eg > 0 || eb > 0) lights[nl++] = i;   // RayTracer.js:65-66
+
+        const double lx = cx - org[0], ly = cy - org[1], lz = cz - org[2];
+        const double ll = lx * lx + ly * ly + lz * lz, r2 = r * r;
+        const double cc = ll - r2;
+        const double scale = std::fmax(std::fmax(ll, r2), 1e-30);
+        const double lnorm = std::sqrt(ll), rad = std::fabs(r);
+        SphereP32 p;
+        std::memset(&p, 0, sizeof p);
+        p.lx = (float)lx; p.ly = (float)ly; p.lz = (float)lz; p.cc = (float)cc;
+        p.md = (float)(PR_RELD * scale);
+        p.kb = (float)(PR_RELD * scale / (PR_RELB * std::sqrt(scale)));
+        p.sgn = cc > 0 ? -1.0f : 1.0f;
+        p.unsure = (std::fabs(cc) <= 4.0 * PR_RELD * scale) ? 1.0f : 0.0f;
+        p.hmd = (float)(0.5 * PR_RELD * scale);
+        p.eb = (float)(PR_RELB * std::sqrt(scale));
+        p.r2 = (float)r2;
+        p.lnorm = (float)(lnorm * (1.0 + 2 * EPS32));
+        p.inv_r = (float)(1.0 / std::fmax(rad, 1e-30));
+        p.hed = (float)(10.0 * EPS32 * rad * lnorm + 2.0 * EPS32 * r2);
+        p32[i] = p;
+        SphereM32 m;
+        m.sr = (float)sr; m.sg = (float)sg; m.sb = (float)sb;
+        m.scmax = (float)std::fmax(sr, std::fmax(sg, sb)) * 1.0000002f;
+        m.er = (float)er; m.eg = (float)eg; m.eb = (float)eb;
+        m.emax = (float)std::fmax(er, std::fmax(eg, eb)) * 1.0000002f;
+        m32[i] = m;
+    }
+    for (int k = 0; k < 3; k++) {
+        h->bg64[k] = bg[k];
+        h->bg32[k] = (float)bg[k];
+    }
+    h->n = n;
+    h->n_lights = nl;
+    h->bg_packed = pack_js(bg[0], bg[1], bg[2]);
+    h->needs_exact = needs_exact ? 1u : 0u;
+    h->off_g64 = L.off_g64; h->off_m64 = L.off_m64; h->off_p32 = L.off_p32;
+    h->off_m32 = L.off_m32; h->off_lights = L.off_lights;
+    return needs_exact;
+}
+
+// rebuild + upload the frame blocks if scene, background or camera changed
+int ensure_uploaded(ptr_ctx* c)
+{
+    if (!c->dirty) return PTR_OK;
+    const BlockLayout L = block_layout(c->n_spheres);
+    c->host_blocks.resize(L.bytes * (size_t)c->n_frames);
+    bool ne = false;
+    for (int f = 0; f < c->n_frames; f++)
+        ne |= build_frame_block(c->host_blocks.data() + L.bytes * (size_t)f, L,
+                                c->soa.data() + (size_t)f * 12u * (size_t)c->n_spheres, c->n_spheres,
+                                c->bg, c->cam.origin);
+    PTR_TRY(grow(c, c->scenes, c->host_blocks.size()));
+    HIP_TRY(c, hipMemcpyAsync(c->scenes.ptr, c->host_blocks.data(), c->host_blocks.size(),
+                              hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->frame_stride = L.bytes;
+    c->needs_exact = ne;
+    c->dirty = false;
+    return PTR_OK;
+}
+
+int check_params(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frames)
+{
+    if (!p) return fail(c, PTR_ERR_INVALID, "params is NULL");
+    if (!c->have_scene) return fail(c, PTR_ERR_NO_SCENE, "no scene uploaded (call ptr_set_scene* first)");
+    if (p->width < 1 || p->height < 1 || p->scan_height < 1)
+        return fail(c, PTR_ERR_INVALID, "width, height and scan_height must be >= 1 (got %d, %d, %d)",
+                    p->width, p->height, p->scan_height);
+    if (p->start_y < -(1 << 30) || p->start_y > (1 << 30))
+        return fail(c, PTR_ERR_INVALID, "start_y out of range (%d)", p->start_y);
+    if (n_frames < 1 || first_frame < 0 || first_frame + n_frames > c->n_frames)
+        return fail(c, PTR_ERR_INVALID, "frames [%d, %d) outside the uploaded sequence of %d",
+                    first_frame, first_frame + n_frames, c->n_frames);
+    if (n_frames > 65535)
+        return fail(c, PTR_ERR_INVALID, "at most 65535 frames per call (got %d)", n_frames);
+    const uint64_t px = (uint64_t)p->width * (uint64_t)p->scan_height * (uint64_t)n_frames;
+    if (px >= (1ull << 32))
+        return fail(c, PTR_ERR_INVALID, "width*scan_height*n_frames must be < 2^32 (got %llu)",
+                    (unsigned long long)px);
+    if ((p->scan_height + PTR_TILE_H - 1) / PTR_TILE_H > 65535)
+        return fail(c, PTR_ERR_INVALID, "scan_height too large (%d)", p->scan_height);
+    if (p->max_depth != 0 || p->spp != 1)
+        return fail(c, PTR_ERR_UNSUPPORTED,
+                    "max_depth=%d spp=%d: only the reference semantics (max_depth 0, spp 1) are built",
+                    p->max_depth, p->spp);
+    if ((p->flags & PTR_MODE_EXACT_F64) && (p->flags & PTR_MODE_F32_ONLY))
+        return fail(c, PTR_ERR_INVALID, "PTR_MODE_EXACT_F64 and PTR_MODE_F32_ONLY are exclusive");
+    return PTR_OK;
+}
+
+int ensure_words(ptr_ctx* c, hipStream_t s)
+{
+    PTR_TRY(grow(c, c->words, WORDS_BYTES));
+    if (c->words_dirty) {
+        HIP_TRY(c, hipMemsetAsync(c->words.ptr, 0, WORDS_BYTES, s));
+        c->words_dirty = false;
+        c->hybrid_calls = 0;
+    }
+    return PTR_OK;
+}
+
+// enqueue the kernels of one render call; no synchronisation
+int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frames,
+                   uint32_t* d_out8, float* d_out32f, hipStream_t s,
+                   const ptr_strips* strips = nullptr, uint64_t frame_stride_px = 0)
+{
+    PTR_TRY(ensure_uploaded(c));
+    PTR_TRY(ensure_words(c, s));
+
+    RenderArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.scenes = static_cast<const unsigned char*>(c->scenes.ptr);
+    a.frame_stride = c->frame_stride;
+    a.first_frame = first_frame;
+    a.width = p->width; a.height = p->height; a.start_y = p->start_y; a.scan_height = p->scan_height;
+    a.flags = p->flags;
+    a.strip_h = strips ? strips->strip_height : 1;
+    a.n_parts = strips ? strips->n_parts : 1;
+    a.part = strips ? strips->part : 0;
+    a.out_frame_stride = frame_stride_px ? frame_stride_px : (uint64_t)p->width * (uint64_t)p->scan_height;
+    for (int k = 0; k < 3; k++) {
+        a.cam.org[k] = c->cam.origin[k];
+        a.cam.right[k] = c->cam.right[k]; a.cam.up[k] = c->cam.up[k]; a.cam.fwd[k] = c->cam.forward[k];
+        a.camf.right[k] = (float)c->cam.right[k]; a.camf.up[k] = (float)c->cam.up[k];
+        a.camf.fwd[k] = (float)c->cam.forward[k];
+    }
+    a.cam.angle = c->cam.tan_half_fov;
+    a.cam.aspect = (double)p->width / (double)p->height;      // RayTracer.js:153
+    a.cam.inv_w = 1.0 / (double)p->width;                     // RayTracer.js:150
+    a.cam.inv_h = 1.0 / (double)p->height;                    // RayTracer.js:151
+    a.cam.general = c->cam_general ? 1 : 0;
+    a.camf.sx = (float)(2.0 * a.cam.inv_w * a.cam.angle * a.cam.aspect);
+    a.camf.ox = (float)(-a.cam.angle * a.cam.aspect);
+    a.camf.sy = (float)(-2.0 * a.cam.inv_h * a.cam.angle);
+    a.camf.oy = (float)(a.cam.angle);
+    a.out8 = d_out8;
+    a.out32f = d_out32f;
+    unsigned char* words = static_cast<unsigned char*>(c->words.ptr);
+    a.stats = reinterpret_cast<unsigned long long*>(words + WORDS_STATS);
+
+    const bool stats = (p->flags & PTR_FLAG_STATS) != 0;
+    const bool exact = stats || (p->flags & PTR_MODE_EXACT_F64) || c->needs_exact;
+    const bool timing = (p->flags & PTR_FLAG_TIMING) != 0;
+    if (stats) HIP_TRY(c, hipMemsetAsync(words + WORDS_STATS, 0, 256, s));
+    if (timing) {
+        for (auto& e : c->ev)
+            if (!e) HIP_TRY(c, hipEventCreate(&e));
+        c->timed_kernels = 0;
+        HIP_TRY(c, hipEventRecord(c->ev[0], s));
+    }
+
+    if (exact) {
+        c->words_dirty |= stats;      // cheap: next call clears everything again
+        HIP_TRY(c, launch_render_exact(a, n_frames, stats, s));
+        if (timing) { HIP_TRY(c, hipEventRecord(c->ev[1], s)); c->timed_kernels = 1; }
+        return PTR_OK;
+    }
+    if (p->flags & PTR_MODE_F32_ONLY) {
+        HIP_TRY(c, launch_render_fast(a, n_frames, false, s));
+        if (timing) { HIP_TRY(c, hipEventRecord(c->ev[1], s)); c->timed_kernels = 1; }
+        return PTR_OK;
+    }
+    // hybrid: float32 kernel fills the queue, float64 kernel drains it
+    const uint64_t px = (uint64_t)p->width * (uint64_t)p->scan_height * (uint64_t)n_frames;
+    PTR_TRY(grow(c, c->queue, (size_t)px * sizeof(uint32_t)));
+    const bool odd = (c->hybrid_calls & 1u) != 0;
+    a.queue = static_cast<uint32_t*>(c->queue.ptr);
+    a.queue_capacity = (uint32_t)px;
+    a.counter = reinterpret_cast<uint32_t*>(words + (odd ? WORDS_COUNTER_B : WORDS_COUNTER_A));
+    a.counter_next = reinterpret_cast<uint32_t*>(words + (odd ? WORDS_COUNTER_A : WORDS_COUNTER_B));
+    c->hybrid_calls++;
+    hipError_t e = launch_render_fast(a, n_frames, true, s);
+    if (e == hipSuccess && timing) e = hipEventRecord(c->ev[1], s);
+    if (e == hipSuccess) {
+        // enough lanes to drain a queue of a few percent of the pixels in one or two sweeps
+        uint64_t blocks = (px / 64 + PTR_BLOCK - 1) / PTR_BLOCK;
+        if (blocks < 1) blocks = 1;
+        if (blocks > 2048) blocks = 2048;
+        e = launch_retrace_exact(a, (int)blocks, s);
+        if (e == hipSuccess && timing) { e = hipEventRecord(c->ev[2], s); c->timed_kernels = 2; }
+    }
+    if (e != hipSuccess) {
+        c->words_dirty = true;
+        return fail(c, PTR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    }
+    return PTR_OK;
+}
+
+int set_scene_locked(ptr_ctx* c, const double* soa, int n, int n_frames)
+{
+    if (n < 0 || n_frames < 1) return fail(c, PTR_ERR_INVALID, "n_spheres must be >= 0 and n_frames >= 1");
+    if (n > 0 && !soa) return fail(c, PTR_ERR_INVALID, "soa is NULL");
+    if ((uint64_t)n * (uint64_t)n_frames > (1ull << 28))
+        return fail(c, PTR_ERR_INVALID, "scene sequence too large (%d spheres x %d frames)", n, n_frames);
+    try {
+        c->soa.assign(soa, soa + (size_t)12 * (size_t)n * (size_t)n_frames);
+    } catch (const std::bad_alloc&) {
+        return fail(c, PTR_ERR_INVALID, "out of host memory copying the scene");
+    }
+    c->n_spheres = n;
+    c->n_frames = n_frames;
+    c->have_scene = true;
+    c->dirty = true;
+    return PTR_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int ptr_abi_version(void) { return PTR_ABI_VERSION; }
+
+const char* ptr_last_error(ptr_ctx* ctx)
+{
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int ptr_create(int device, ptr_ctx** out)
+{
+    if (!out) return fail(nullptr, PTR_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count < 1) {
+        (void)hipGetLastError();
+        return fail(nullptr, PTR_ERR_NO_DEVICE,
+                    "no HIP device available (%s); this library has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    }
+    if (device < 0 || device >= count)
+        return fail(nullptr, PTR_ERR_INVALID, "device %d out of range (0..%d)", device, count - 1);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(nullptr, PTR_ERR_NO_DEVICE, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return fail(nullptr, PTR_ERR_NO_DEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, PTR_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
+                    device, prop.gcnArchName);
+    ptr_ctx* c = new (std::nothrow) ptr_ctx();
+    if (!c) return fail(nullptr, PTR_ERR_INVALID, "out of host memory");
+    c->device = device;
+    default_camera(c->cam);
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(nullptr, PTR_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return PTR_OK;
+}
+
+void ptr_destroy(ptr_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+    for (DeviceBuffer* b : {&c->scenes, &c->queue, &c->words, &c->out8, &c->out32f, &c->tr_in_o,
+                            &c->tr_in_d, &c->tr_rgb, &c->tr_el, &c->tr_hit, &c->tr_nrm})
+        if (b->ptr) (void)hipFree(b->ptr);
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int ptr_set_scene_sequence_f64(ptr_ctx* c, const double* soa, int n_spheres, int n_frames)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    return set_scene_locked(c, soa, n_spheres, n_frames);
+}
+
+int ptr_set_scene_f64(ptr_ctx* c, const double* soa, int n_spheres)
+{
+    return ptr_set_scene_sequence_f64(c, soa, n_spheres, 1);
+}
+
+int ptr_set_scene(ptr_ctx* c, const float* soa, int n_spheres)
+{
+    if (!c) return PTR_ERR_INVALID;
+    if (n_spheres < 0) { std::lock_guard<std::mutex> g(c->mu); return fail(c, PTR_ERR_INVALID, "n_spheres < 0"); }
+    if (n_spheres > 0 && !soa) { std::lock_guard<std::mutex> g(c->mu); return fail(c, PTR_ERR_INVALID, "soa is NULL"); }
+    std::vector<double> tmp((size_t)12 * (size_t)n_spheres);
+    for (size_t k = 0; k < tmp.size(); k++) tmp[k] = (double)soa[k];
+    return ptr_set_scene_sequence_f64(c, tmp.data(), n_spheres, 1);
+}
+
+int ptr_set_background_f64(ptr_ctx* c, const double rgb[3])
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!rgb) return fail(c, PTR_ERR_INVALID, "rgb is NULL");
+    for (int k = 0; k < 3; k++) c->bg[k] = rgb[k];
+    c->dirty = true;
+    return PTR_OK;
+}
+
+int ptr_set_background(ptr_ctx* c, const float rgb[3])
+{
+    if (!c) return PTR_ERR_INVALID;
+    if (!rgb) { std::lock_guard<std::mutex> g(c->mu); return fail(c, PTR_ERR_INVALID, "rgb is NULL"); }
+    const double d[3] = {(double)rgb[0], (double)rgb[1], (double)rgb[2]};
+    return ptr_set_background_f64(c, d);
+}
+
+int ptr_set_camera(ptr_ctx* c, const ptr_camera* cam)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!cam) {
+        default_camera(c->cam);
+        c->cam_general = false;
+    } else {
+        const double* v = cam->origin;
+        for (int k = 0; k < 13; k++)
+            if (!(std::fabs(v[k]) <= 1e15)) return fail(c, PTR_ERR_INVALID, "camera field %d is not finite", k);
+        if (!(cam->tan_half_fov > 0)) return fail(c, PTR_ERR_INVALID, "tan_half_fov must be > 0");
+        c->cam = *cam;
+        // the reference layout of the basis keeps the reference formula dir = (xx, yy, -1)
+        c->cam_general = !(cam->right[0] == 1 && cam->right[1] == 0 && cam->right[2] == 0 &&
+                           cam->up[0] == 0 && cam->up[1] == 1 && cam->up[2] == 0 &&
+                           cam->forward[0] == 0 && cam->forward[1] == 0 && cam->forward[2] == -1);
+    }
+    c->dirty = true;     // camera-relative sphere terms depend on the origin
+    return PTR_OK;
+}
+
+int ptr_render_device(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frames,
+                      void* d_rgba8, void* d_rgba32f, void* stream)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    PTR_TRY(check_params(c, p, first_frame, n_frames));
+    if (!d_rgba8) return fail(c, PTR_ERR_INVALID, "d_rgba8 is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    return enqueue_render(c, p, first_frame, n_frames, static_cast<uint32_t*>(d_rgba8),
+                          static_cast<float*>(d_rgba32f), s);
+}
+
+int ptr_strip_rows(const ptr_strips* s, int height)
+{
+    if (!s || s->n_parts < 1 || s->part < 0 || s->part >= s->n_parts || s->strip_height < 1 || height < 0)
+        return PTR_ERR_INVALID;
+    const int sh = s->strip_height;
+    const int n_strips = (height + sh - 1) / sh;
+    int rows = 0;
+    for (int k = s->part; k < n_strips; k += s->n_parts) {
+        const int y0 = k * sh, y1 = y0 + sh < height ? y0 + sh : height;
+        rows += y1 - y0;
+    }
+    return rows;
+}
+
+int ptr_render_strips_device(ptr_ctx* c, const ptr_params* p, const ptr_strips* st,
+                             int first_frame, int n_frames, void* d_rgba8, void* d_rgba32f,
+                             uint64_t frame_stride_px, void* stream)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    PTR_TRY(check_params(c, p, first_frame, n_frames));
+    if (!d_rgba8) return fail(c, PTR_ERR_INVALID, "d_rgba8 is NULL");
+    if (!st) return fail(c, PTR_ERR_INVALID, "strips is NULL");
+    const int rows = ptr_strip_rows(st, p->height);
+    if (rows < 0) return fail(c, PTR_ERR_INVALID, "bad strip description");
+    if (p->scan_height != rows || p->start_y != 0)
+        return fail(c, PTR_ERR_INVALID, "strips: scan_height must be %d (got %d) and start_y 0 (got %d)",
+                    rows, p->scan_height, p->start_y);
+    if (p->flags & PTR_QUIRK_ROW_SHIFT)
+        return fail(c, PTR_ERR_INVALID, "PTR_QUIRK_ROW_SHIFT cannot be combined with strips");
+    if (frame_stride_px && frame_stride_px < (uint64_t)p->width * (uint64_t)rows)
+        return fail(c, PTR_ERR_INVALID, "frame_stride_px smaller than one frame");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    return enqueue_render(c, p, first_frame, n_frames, static_cast<uint32_t*>(d_rgba8),
+                          static_cast<float*>(d_rgba32f), s, st, frame_stride_px);
+}
+
+int ptr_sync(ptr_ctx* c)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PTR_OK;
+}
+
+int ptr_render(ptr_ctx* c, const ptr_params* p, uint32_t* out_rgba8, float* out_rgba32f)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    PTR_TRY(check_params(c, p, 0, 1));
+    if (!out_rgba8) return fail(c, PTR_ERR_INVALID, "out_rgba8 is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t px = (size_t)p->width * (size_t)p->scan_height;
+    PTR_TRY(grow(c, c->out8, px * 4));
+    if (out_rgba32f) PTR_TRY(grow(c, c->out32f, px * 16));
+    PTR_TRY(enqueue_render(c, p, 0, 1, static_cast<uint32_t*>(c->out8.ptr),
+                           out_rgba32f ? static_cast<float*>(c->out32f.ptr) : nullptr, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out_rgba8, c->out8.ptr, px * 4, hipMemcpyDeviceToHost, c->stream));
+    if (out_rgba32f)
+        HIP_TRY(c, hipMemcpyAsync(out_rgba32f, c->out32f.ptr, px * 16, hipMemcpyDeviceToHost, c->stream));
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        c->words_dirty = true;
+        return fail(c, PTR_ERR_HIP, "render failed: %s", hipGetErrorString(e));
+    }
+    return PTR_OK;
+}
+
+int ptr_trace_batch_f64(ptr_ctx* c, const double* origins, const double* dirs, int n,
+                        double* out_rgb, int32_t* out_element, double* out_hit, double* out_normal)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_scene) return fail(c, PTR_ERR_NO_SCENE, "no scene uploaded (call ptr_set_scene* first)");
+    if (n < 0) return fail(c, PTR_ERR_INVALID, "n < 0");
+    if (n == 0) return PTR_OK;
+    if (!dirs || !out_rgb) return fail(c, PTR_ERR_INVALID, "dirs_xyz / out_rgb64 is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    PTR_TRY(ensure_uploaded(c));
+    const size_t v3 = (size_t)n * 3 * sizeof(double);
+    PTR_TRY(grow(c, c->tr_in_d, v3));
+    PTR_TRY(grow(c, c->tr_rgb, v3));
+    if (origins) PTR_TRY(grow(c, c->tr_in_o, v3));
+    if (out_element) PTR_TRY(grow(c, c->tr_el, (size_t)n * sizeof(int32_t)));
+    if (out_hit) PTR_TRY(grow(c, c->tr_hit, v3));
+    if (out_normal) PTR_TRY(grow(c, c->tr_nrm, v3));
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipMemcpyAsync(c->tr_in_d.ptr, dirs, v3, hipMemcpyHostToDevice, s));
+    if (origins) HIP_TRY(c, hipMemcpyAsync(c->tr_in_o.ptr, origins, v3, hipMemcpyHostToDevice, s));
+    TraceArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.scene = static_cast<const unsigned char*>(c->scenes.ptr);
+    a.origins = origins ? static_cast<const double*>(c->tr_in_o.ptr) : nullptr;
+    a.dirs = static_cast<const double*>(c->tr_in_d.ptr);
+    a.n = n;
+    for (int k = 0; k < 3; k++) a.org[k] = c->cam.origin[k];
+    a.out_rgb = static_cast<double*>(c->tr_rgb.ptr);
+    a.out_element = out_element ? static_cast<int32_t*>(c->tr_el.ptr) : nullptr;
+    a.out_hit = out_hit ? static_cast<double*>(c->tr_hit.ptr) : nullptr;
+    a.out_normal = out_normal ? static_cast<double*>(c->tr_nrm.ptr) : nullptr;
+    HIP_TRY(c, launch_trace_batch_exact(a, s));
+    HIP_TRY(c, hipMemcpyAsync(out_rgb, c->tr_rgb.ptr, v3, hipMemcpyDeviceToHost, s));
+    if (out_element) HIP_TRY(c, hipMemcpyAsync(out_element, c->tr_el.ptr, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (out_hit) HIP_TRY(c, hipMemcpyAsync(out_hit, c->tr_hit.ptr, v3, hipMemcpyDeviceToHost, s));
+    if (out_normal) HIP_TRY(c, hipMemcpyAsync(out_normal, c->tr_nrm.ptr, v3, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return PTR_OK;
+}
+
+int ptr_trace_batch(ptr_ctx* c, const float* dirs_xyz, int n,
+                    uint8_t* out_rgb, float* out_hit_xyz, float* out_normal_xyz)
+{
+    if (!c) return PTR_ERR_INVALID;
+    if (n < 0 || (n > 0 && (!dirs_xyz || !out_rgb))) {
+        std::lock_guard<std::mutex> g(c->mu);
+        return fail(c, PTR_ERR_INVALID, "bad arguments to ptr_trace_batch");
+    }
+    if (n == 0) return PTR_OK;
+    std::vector<double> d((size_t)n * 3), rgb((size_t)n * 3), hit, nrm;
+    for (size_t k = 0; k < d.size(); k++) d[k] = (double)dirs_xyz[k];
+    if (out_hit_xyz) hit.resize((size_t)n * 3);
+    if (out_normal_xyz) nrm.resize((size_t)n * 3);
+    PTR_TRY(ptr_trace_batch_f64(c, nullptr, d.data(), n, rgb.data(), nullptr,
+                                out_hit_xyz ? hit.data() : nullptr, out_normal_xyz ? nrm.data() : nullptr));
+    for (size_t k = 0; k < rgb.size(); k++)     // RayTracer.js:105-112
+        out_rgb[k] = (uint8_t)(js_to_uint32(js_round(js_min1(rgb[k]) * 255.0)) & 0xffu);
+    for (size_t k = 0; k < hit.size(); k++) out_hit_xyz[k] = (float)hit[k];
+    for (size_t k = 0; k < nrm.size(); k++) out_normal_xyz[k] = (float)nrm[k];
+    return PTR_OK;
+}
+
+int ptr_get_kernel_ms(ptr_ctx* c, float* main_ms, float* retrace_ms)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!main_ms || !retrace_ms) return fail(c, PTR_ERR_INVALID, "output pointer is NULL");
+    *main_ms = 0.0f; *retrace_ms = 0.0f;
+    if (c->timed_kernels < 1) return fail(c, PTR_ERR_INVALID, "no call with PTR_FLAG_TIMING yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventSynchronize(c->ev[c->timed_kernels]));
+    HIP_TRY(c, hipEventElapsedTime(main_ms, c->ev[0], c->ev[1]));
+    if (c->timed_kernels == 2) HIP_TRY(c, hipEventElapsedTime(retrace_ms, c->ev[1], c->ev[2]));
+    return PTR_OK;
+}
+
+int ptr_get_stats(ptr_ctx* c, ptr_stats* out)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!out) return fail(c, PTR_ERR_INVALID, "out is NULL");
+    std::memset(out, 0, sizeof *out);
+    if (!c->words.ptr) return PTR_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned long long w[8];
+    HIP_TRY(c, hipMemcpy(w, static_cast<unsigned char*>(c->words.ptr) + WORDS_STATS, sizeof w, hipMemcpyDeviceToHost));
+    out->primary = w[0]; out->hits = w[1]; out->shadow_rays = w[2];
+    out->exit_tca = w[3]; out->exit_d2 = w[4]; out->exit_hit = w[5]; out->retraced = w[6];
+    return PTR_OK;
+}
+
+}  // extern "C"

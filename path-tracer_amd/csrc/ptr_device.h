@@ -1,0 +1,173 @@
+// ptr_device.h — data layout shared by the host side of the C ABI and the gfx950 kernels.
+//
+// One "frame block" per scene of a sequence lives in HBM, built on the host by
+// build_frame_block() (ptr_api.hip) and read by every workgroup through wave-uniform
+// (scalar) loads: the sphere loops index with a wave-uniform counter, so the geometry sits
+// in SGPRs and costs no vector memory traffic or LDS.  Per-lane reads happen only once per
+// pixel, for the material of the winning sphere.
+#pragma once
+#include <stdint.h>
+
+#define PTR_INFINITY 1e8      // RT/src/RayTracer.js:6 — finite far clip
+#define PTR_BIAS     1e-4     // RT/src/RayTracer.js:52
+
+#define PTR_TILE_W 32         // workgroup tile: 4 waves side by side, each an 8x8 pixel tile
+#define PTR_TILE_H 8
+#define PTR_BLOCK  256
+
+namespace ptr {
+
+// ---- per-frame scene block -------------------------------------------------------------
+struct alignas(16) FrameHeader {          // 128 bytes
+    int32_t  n;                           // elements
+    int32_t  n_lights;                    // emissive elements, scene order
+    uint32_t bg_packed;                   // pack_js(bg64): what a miss stores
+    uint32_t needs_exact;                 // 1: scene has values the f32 path cannot represent
+    double   bg64[3];
+    float    bg32[3];
+    float    pad0;
+    uint32_t off_g64, off_m64, off_p32, off_m32, off_lights, off_pad;   // byte offsets in block
+    uint32_t pad1[10];
+};
+static_assert(sizeof(FrameHeader) == 128, "FrameHeader layout");
+
+struct alignas(16) SphereG64 { double cx, cy, cz, r2; };            // exact geometry (Sphere.js:9-11)
+struct alignas(16) SphereM64 { double sr, sg, sb, er, eg, eb; };    // exact material (Material.js:5-10)
+
+// float32 path: everything is relative to the (wave-uniform) camera origin, computed in
+// float64 on the host and rounded once, so a far-away camera costs no float32 precision.
+// Read with wave-uniform indices -> scalar loads (s_load_dwordx8 / x4 per sphere); the
+// winner's record is gathered per lane once per pixel.
+// eps below is the float32 unit roundoff 2^-24; "scale" = max(|l|^2, r^2).
+struct alignas(16) SphereP32 {
+    // group 0: primary hit test
+    float lx, ly, lz;     // l = C - origin
+    float cc;             // |l|^2 - r^2   (sign: origin outside (+) / inside (-) the sphere)
+    // group 1: primary hit test, "not sure" bands
+    float md;             // bound on the error of disc = b^2 - cc          (24 eps scale)
+    float kb;             // md / eb, eb = bound on the error of b = l.d    (10 eps sqrt(scale))
+    float sgn;            // -1: outside, nearest root is b - thc;  +1: inside, root is b + thc
+    float unsure;         // 1.0f: |cc| too small to trust its sign -> any hit on it is re-traced
+    // group 2: ordering band, shadow test
+    float hmd;            // md / 2:  |dt| <= hmd / thc + eb
+    float eb;
+    float r2;             // radius^2
+    float lnorm;          // |l|
+    // group 3: winner refinement
+    float inv_r;          // 1 / radius
+    float hed;            // half the error bound of disc' = r^2 - |l x d|^2  (10 eps r |l| + 2 eps r^2)
+    float pad0, pad1;
+};
+static_assert(sizeof(SphereP32) == 64, "SphereP32 layout");
+// material, gathered per lane for the winning sphere; scmax/emax = largest channel
+struct alignas(16) SphereM32 { float sr, sg, sb, scmax, er, eg, eb, emax; };
+
+struct FrameView {
+    const FrameHeader* h;
+    const SphereG64* g64;
+    const SphereM64* m64;
+    const SphereP32* p32;
+    const SphereM32* m32;
+    const int32_t*   lights;
+};
+
+__host__ __device__ inline FrameView frame_view(const unsigned char* block)
+{
+    FrameView v;
+    v.h = reinterpret_cast<const FrameHeader*>(block);
+    v.g64 = reinterpret_cast<const SphereG64*>(block + v.h->off_g64);
+    v.m64 = reinterpret_cast<const SphereM64*>(block + v.h->off_m64);
+    v.p32 = reinterpret_cast<const SphereP32*>(block + v.h->off_p32);
+    v.m32 = reinterpret_cast<const SphereM32*>(block + v.h->off_m32);
+    v.lights = reinterpret_cast<const int32_t*>(block + v.h->off_lights);
+    return v;
+}
+
+// ---- kernel arguments (passed by value) --------------------------------------------------
+struct CameraArgs {
+    double org[3], right[3], up[3], fwd[3];
+    double angle;          // tan(half fov)          RayTracer.js:154
+    double aspect;         // width/height           RayTracer.js:153
+    double inv_w, inv_h;   // 1/width, 1/height      RayTracer.js:150-151
+    int32_t general;       // 0: reference camera, dir = (xx, yy, -1)
+    int32_t pad;
+};
+
+// float32 camera: xx = (x+0.5)*sx + ox, yy = (y+0.5)*sy + oy  (RayTracer.js:171-172 refactored)
+struct CameraF32 {
+    float sx, ox, sy, oy;
+    float right[3], up[3], fwd[3];
+};
+
+struct RenderArgs {
+    const unsigned char* scenes;     // frame blocks, frame_stride bytes apart
+    uint64_t  frame_stride;
+    int32_t   first_frame;
+    int32_t   width, height, start_y, scan_height;
+    uint32_t  flags;                 // PTR_QUIRK_ROW_SHIFT etc. (include/ptr.h)
+    int32_t   strip_h, n_parts, part; // cyclic strips: local row r is image row global_y(r); n_parts 1 = band
+    uint64_t  out_frame_stride;      // pixels between consecutive frames in out8 / out32f
+    CameraArgs cam;
+    CameraF32  camf;
+    uint32_t* out8;                  // n_frames * width * scan_height
+    float*    out32f;                // nullable, n_frames * width * scan_height * 4
+    uint32_t* queue;                 // hybrid: global pixel ids to re-trace
+    uint32_t* counter;               // hybrid: queue fill (this call's counter word)
+    uint32_t* counter_next;          // hybrid: the other counter word, zeroed for the next call
+    uint32_t  queue_capacity;
+    unsigned long long* stats;       // nullable; 8 words, see ptr_stats
+};
+
+struct TraceArgs {
+    const unsigned char* scene;      // one frame block
+    const double* origins;           // nullable -> cam origin
+    const double* dirs;
+    int32_t n;
+    double org[3];
+    double* out_rgb;                 // 3 per ray
+    int32_t* out_element;            // nullable
+    double* out_hit;                 // nullable
+    double* out_normal;              // nullable
+};
+
+// image row of local row `row` (band: start_y + row; cyclic strips: strip k belongs to part k % n_parts)
+__host__ __device__ inline int global_y(const RenderArgs& a, int row)
+{
+    if (a.n_parts <= 1) return a.start_y + row;
+    const int ls = row / a.strip_h;
+    return a.start_y + (ls * a.n_parts + a.part) * a.strip_h + (row - ls * a.strip_h);
+}
+
+// ---- JS number semantics of the final pack (RayTracer.js:179-192) -------------------------
+__host__ __device__ inline double js_min1(double c) { return (c != c) ? c : (c < 1.0 ? c : 1.0); }
+__host__ __device__ inline double js_max0(double x) { return (x != x) ? x : (x > 0.0 ? x : 0.0); }
+
+__host__ __device__ inline double js_round(double x)
+{
+    // Math.round: nearest integer, ties towards +infinity; NaN and +-Infinity pass through
+    if (!(x - x == 0.0)) return x;
+    double f = __builtin_floor(x);
+    return (x - f >= 0.5) ? f + 1.0 : f;
+}
+
+__host__ __device__ inline uint32_t js_to_uint32(double x)
+{
+    // ECMAScript ToInt32/ToUint32 bit pattern
+    if (!(x - x == 0.0)) return 0u;
+    double t = __builtin_trunc(x);
+    if (t >= -2147483648.0 && t < 4294967296.0)
+        return t < 0 ? (uint32_t)(int32_t)t : (uint32_t)t;
+    double m = __builtin_fmod(t, 4294967296.0);
+    if (m < 0) m += 4294967296.0;
+    return (uint32_t)m;
+}
+
+__host__ __device__ inline uint32_t pack_js(double r, double g, double b)
+{
+    double rr = js_round(js_min1(r) * 255.0);
+    double gg = js_round(js_min1(g) * 255.0);
+    double bb = js_round(js_min1(b) * 255.0);
+    return (255u << 24) | (js_to_uint32(bb) << 16) | (js_to_uint32(gg) << 8) | js_to_uint32(rr);
+}
+
+}  // namespace ptr

@@ -1,0 +1,239 @@
+// ptr_kernels_exact.hip — float64 kernels that follow the reference operation for operation.
+//
+// Compiled with -ffp-contract=off: every '*' and '+' below is one IEEE-754 double rounding in
+// the same left-to-right order as the JavaScript source, f64 sqrt and divide are the correctly
+// rounded device forms, so results are bit-identical to the reference
+// (RT/src/RayTracer.js:18-95,132-197, RT/src/Sphere.js:15-51, RT/src/Vector3.js:23-37).
+//
+// Used for (1) PTR_MODE_EXACT_F64 whole-band renders, (2) the hybrid mode's re-trace of
+// queued pixels, (3) ptr_trace_batch_f64.
+#include <hip/hip_runtime.h>
+#include "ptr_device.h"
+#include "ptr_kernels.h"
+
+namespace ptr {
+
+struct V3 { double x, y, z; };
+
+// Vector3.normalize (Vector3.js:23-33): invLen = 1/sqrt(len2), then three multiplies
+__device__ __forceinline__ void normalize_js(V3& v)
+{
+    double len2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    if (len2 > 0) {
+        double inv = 1.0 / __builtin_sqrt(len2);
+        v.x *= inv; v.y *= inv; v.z *= inv;
+    }
+}
+
+struct ExactHit { int element; double tnear; V3 P, N; };
+
+// stats word indices (match ptr_stats in include/ptr.h)
+enum { ST_PRIMARY = 0, ST_HITS, ST_SHADOW, ST_EXIT_TCA, ST_EXIT_D2, ST_EXIT_HIT, ST_RETRACED };
+
+template <bool STATS>
+__device__ __forceinline__ void count(unsigned long long* stats, int which)
+{
+    if constexpr (STATS) atomicAdd(&stats[which], 1ull);
+}
+
+// RayTracer.trace (RayTracer.js:18-95).  o, d: ray; returns unclamped colour.
+template <bool STATS>
+__device__ V3 trace_exact(const FrameView& fv, V3 o, V3 d, ExactHit* hit, unsigned long long* stats)
+{
+    const int n = fv.h->n;
+    count<STATS>(stats, ST_PRIMARY);
+
+    // nearest hit in scene order, strict '<' (RayTracer.js:26-41, Sphere.js:15-33)
+    double tnear = PTR_INFINITY;
+    int element = -1;
+    for (int i = 0; i < n; i++) {
+        const SphereG64 s = fv.g64[i];                 // wave-uniform address -> scalar load
+        double lx = s.cx - o.x, ly = s.cy - o.y, lz = s.cz - o.z;
+        double tca = lx * d.x + ly * d.y + lz * d.z;
+        if (tca < 0) { count<STATS>(stats, ST_EXIT_TCA); continue; }
+        double d2 = (lx * lx + ly * ly + lz * lz) - tca * tca;
+        if (d2 > s.r2) { count<STATS>(stats, ST_EXIT_D2); continue; }
+        count<STATS>(stats, ST_EXIT_HIT);
+        double thc = __builtin_sqrt(s.r2 - d2);
+        double t0 = tca - thc, t1 = tca + thc;
+        if (t0 < 0) t0 = t1;
+        if (t0 < tnear) { tnear = t0; element = i; }
+    }
+    if (hit) { hit->element = element; hit->tnear = tnear; }
+    if (element < 0) {                                 // RayTracer.js:43-46
+        if (hit) { hit->P = V3{0, 0, 0}; hit->N = V3{0, 0, 0}; }
+        return V3{fv.h->bg64[0], fv.h->bg64[1], fv.h->bg64[2]};
+    }
+    count<STATS>(stats, ST_HITS);
+
+    // hit frame (RayTracer.js:48-58, Sphere.js:47-51)
+    const SphereG64 se = fv.g64[element];              // per-lane gather
+    const SphereM64 me = fv.m64[element];
+    V3 P{o.x + d.x * tnear, o.y + d.y * tnear, o.z + d.z * tnear};
+    V3 N{P.x - se.cx, P.y - se.cy, P.z - se.cz};
+    normalize_js(N);
+    if (d.x * N.x + d.y * N.y + d.z * N.z > 0) { N.x = -N.x; N.y = -N.y; N.z = -N.z; }
+    if (hit) { hit->P = P; hit->N = N; }
+
+    // shadow-ray origin (RayTracer.js:77, recomputed per j there; same value)
+    const V3 so{P.x + N.x * PTR_BIAS, P.y + N.y * PTR_BIAS, P.z + N.z * PTR_BIAS};
+
+    // every emissive element, scene order (RayTracer.js:61-91)
+    V3 acc{0, 0, 0};
+    const int nl = fv.h->n_lights;
+    for (int k = 0; k < nl; k++) {
+        const int i = fv.lights[k];
+        const SphereG64 li = fv.g64[i];
+        const SphereM64 lm = fv.m64[i];
+        count<STATS>(stats, ST_SHADOW);
+        V3 L{li.cx - P.x, li.cy - P.y, li.cz - P.z};
+        normalize_js(L);
+        double tr = 1.0;
+        for (int j = 0; j < n; j++) {
+            if (j == i) continue;
+            const SphereG64 s = fv.g64[j];
+            double lx = s.cx - so.x, ly = s.cy - so.y, lz = s.cz - so.z;
+            double tca = lx * L.x + ly * L.y + lz * L.z;
+            if (tca < 0) { count<STATS>(stats, ST_EXIT_TCA); continue; }
+            double d2 = (lx * lx + ly * ly + lz * lz) - tca * tca;
+            if (d2 > s.r2) { count<STATS>(stats, ST_EXIT_D2); continue; }
+            count<STATS>(stats, ST_EXIT_HIT);
+            tr = 0.0;                                  // any hit blocks; distance ignored (F7)
+            break;
+        }
+        double ratio = js_max0(N.x * L.x + N.y * L.y + N.z * L.z);
+        acc.x += (me.sr * tr) * (lm.er * ratio);       // RayTracer.js:89
+        acc.y += (me.sg * tr) * (lm.eg * ratio);
+        acc.z += (me.sb * tr) * (lm.eb * ratio);
+    }
+    acc.x += me.er; acc.y += me.eg; acc.z += me.eb;    // RayTracer.js:93
+    return acc;
+}
+
+// camera ray for pixel (x, y) of the full image (RayTracer.js:171-174)
+__device__ __forceinline__ V3 primary_dir_exact(const CameraArgs& c, int x, int y)
+{
+    double xx = (2 * ((x + 0.5) * c.inv_w) - 1) * c.angle * c.aspect;
+    double yy = (1 - 2 * ((y + 0.5) * c.inv_h)) * c.angle;
+    V3 d;
+    if (c.general) {
+        d.x = xx * c.right[0] + yy * c.up[0] + c.fwd[0];
+        d.y = xx * c.right[1] + yy * c.up[1] + c.fwd[1];
+        d.z = xx * c.right[2] + yy * c.up[2] + c.fwd[2];
+    } else {
+        d = V3{xx, yy, -1.0};
+    }
+    normalize_js(d);
+    return d;
+}
+
+// where pixel (x, row) of the band is stored; -1 = dropped (RayTracer.js:169 under the quirk)
+__device__ __forceinline__ long long store_index(const RenderArgs& a, int x, int row)
+{
+    if (a.flags & 0x0001u /* PTR_QUIRK_ROW_SHIFT */)
+        return (long long)a.width * row - (a.width - x);
+    return (long long)a.width * row + x;
+}
+
+template <bool STATS>
+__device__ __forceinline__ void shade_and_store_exact(const RenderArgs& a, int frame, int x, int row)
+{
+    const unsigned char* block = a.scenes + (uint64_t)(a.first_frame + frame) * a.frame_stride;
+    const FrameView fv = frame_view(block);
+    const long long idx = store_index(a, x, row);
+    const bool quirk = (a.flags & 0x0001u) != 0;
+    if (quirk && row == 0) {
+        // the reference drops this row and never writes the band's last stored row
+        a.out8[frame * a.out_frame_stride + (uint64_t)a.width * (a.scan_height - 1) + x] = 0u;
+        if (!a.out32f && !STATS) return;
+    }
+    V3 o{a.cam.org[0], a.cam.org[1], a.cam.org[2]};
+    V3 d = primary_dir_exact(a.cam, x, global_y(a, row));
+    V3 c = trace_exact<STATS>(fv, o, d, nullptr, a.stats);
+    if (idx >= 0) a.out8[frame * a.out_frame_stride + idx] = pack_js(c.x, c.y, c.z);
+    if (a.out32f) {
+        float* p = a.out32f + 4 * (frame * a.out_frame_stride + (uint64_t)a.width * row + x);
+        p[0] = (float)c.x; p[1] = (float)c.y; p[2] = (float)c.z; p[3] = 1.0f;
+    }
+}
+
+// one pixel per lane, 8x8 pixels per wave, 32x8 per workgroup, blockIdx.z = frame
+template <bool STATS>
+__global__ void __launch_bounds__(PTR_BLOCK) render_exact_kernel(RenderArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * PTR_TILE_W + wave * 8 + (lane & 7);
+    const int row = blockIdx.y * PTR_TILE_H + (lane >> 3);
+    if (x >= a.width || row >= a.scan_height) return;
+    shade_and_store_exact<STATS>(a, blockIdx.z, x, row);
+}
+
+// hybrid mode, second kernel: re-trace the pixels the float32 kernel was not sure about.
+// Fixed grid, grid-stride over the queue; the fill count is read from device memory, so the
+// host never synchronises between the two kernels.
+__global__ void __launch_bounds__(PTR_BLOCK) retrace_exact_kernel(RenderArgs a)
+{
+    const uint32_t fill = *a.counter;
+    const uint32_t count = fill < a.queue_capacity ? fill : a.queue_capacity;
+    const uint64_t frame_px = (uint64_t)a.width * (uint64_t)a.scan_height;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < count; q += gridDim.x * blockDim.x) {
+        const uint64_t gid = a.queue[q];
+        const int frame = (int)(gid / frame_px);
+        const uint32_t pix = (uint32_t)(gid - (uint64_t)frame * frame_px);
+        const int row = (int)(pix / (uint32_t)a.width), x = (int)(pix - (uint32_t)row * a.width);
+        const unsigned char* block = a.scenes + (uint64_t)(a.first_frame + frame) * a.frame_stride;
+        const FrameView fv = frame_view(block);
+        V3 o{a.cam.org[0], a.cam.org[1], a.cam.org[2]};
+        V3 d = primary_dir_exact(a.cam, x, global_y(a, row));
+        V3 c = trace_exact<false>(fv, o, d, nullptr, nullptr);
+        const long long idx = store_index(a, x, row);
+        if (idx >= 0) a.out8[frame * a.out_frame_stride + idx] = pack_js(c.x, c.y, c.z);
+        if (a.out32f) {
+            float* p = a.out32f + 4 * (frame * a.out_frame_stride + (uint64_t)a.width * row + x);
+            p[0] = (float)c.x; p[1] = (float)c.y; p[2] = (float)c.z; p[3] = 1.0f;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *a.counter_next = 0u;                          // ready for the next call on this stream
+        if (a.stats) a.stats[ST_RETRACED] = count;
+    }
+}
+
+__global__ void __launch_bounds__(PTR_BLOCK) trace_batch_exact_kernel(TraceArgs a)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.n) return;
+    const FrameView fv = frame_view(a.scene);
+    V3 o = a.origins ? V3{a.origins[3 * k], a.origins[3 * k + 1], a.origins[3 * k + 2]}
+                     : V3{a.org[0], a.org[1], a.org[2]};
+    V3 d{a.dirs[3 * k], a.dirs[3 * k + 1], a.dirs[3 * k + 2]};
+    ExactHit h;
+    V3 c = trace_exact<false>(fv, o, d, &h, nullptr);
+    a.out_rgb[3 * k] = c.x; a.out_rgb[3 * k + 1] = c.y; a.out_rgb[3 * k + 2] = c.z;
+    if (a.out_element) a.out_element[k] = h.element;
+    if (a.out_hit) { a.out_hit[3 * k] = h.P.x; a.out_hit[3 * k + 1] = h.P.y; a.out_hit[3 * k + 2] = h.P.z; }
+    if (a.out_normal) { a.out_normal[3 * k] = h.N.x; a.out_normal[3 * k + 1] = h.N.y; a.out_normal[3 * k + 2] = h.N.z; }
+}
+
+// ---- launchers (called from ptr_api.hip) --------------------------------------------------
+hipError_t launch_render_exact(const RenderArgs& a, int n_frames, bool stats, hipStream_t s)
+{
+    dim3 grid((a.width + PTR_TILE_W - 1) / PTR_TILE_W, (a.scan_height + PTR_TILE_H - 1) / PTR_TILE_H, n_frames);
+    if (stats) hipLaunchKernelGGL(render_exact_kernel<true>, grid, dim3(PTR_BLOCK), 0, s, a);
+    else       hipLaunchKernelGGL(render_exact_kernel<false>, grid, dim3(PTR_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_retrace_exact(const RenderArgs& a, int blocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(retrace_exact_kernel, dim3(blocks), dim3(PTR_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_trace_batch_exact(const TraceArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(trace_batch_exact_kernel, dim3((a.n + PTR_BLOCK - 1) / PTR_BLOCK), dim3(PTR_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace ptr

@@ -1,0 +1,271 @@
+"""ptr_amd — thin ctypes binding over the C ABI of include/ptr.h (libptr_hip.so).
+
+Plumbing for pytest and bench.py only; the product's host language is JavaScript
+(path-tracer_amd/js).  There is no CPU fallback: importing works without a GPU (so the
+symbol table can be checked), creating a Renderer does not.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libptr_hip.so"))
+
+QUIRK_ROW_SHIFT = 0x0001
+MODE_EXACT_F64 = 0x0002
+MODE_F32_ONLY = 0x0004
+FLAG_STATS = 0x0008
+FLAG_TIMING = 0x0010
+DEBUG_REASONS = 0x8000
+
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NO_SCENE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+
+# every symbol include/ptr.h declares (tests check the library exports exactly these)
+SYMBOLS = [
+    "ptr_abi_version", "ptr_create", "ptr_destroy", "ptr_last_error",
+    "ptr_set_scene", "ptr_set_scene_f64", "ptr_set_scene_sequence_f64",
+    "ptr_set_background", "ptr_set_background_f64", "ptr_set_camera",
+    "ptr_render", "ptr_render_device", "ptr_render_strips_device", "ptr_strip_rows", "ptr_sync",
+    "ptr_trace_batch", "ptr_trace_batch_f64", "ptr_get_stats", "ptr_get_kernel_ms",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("start_y", C.c_int32),
+                ("scan_height", C.c_int32), ("max_depth", C.c_int32), ("spp", C.c_int32),
+                ("seed", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("origin", C.c_double * 3), ("right", C.c_double * 3), ("up", C.c_double * 3),
+                ("forward", C.c_double * 3), ("tan_half_fov", C.c_double)]
+
+
+class Strips(C.Structure):
+    _fields_ = [("n_parts", C.c_int32), ("part", C.c_int32), ("strip_height", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class StripPart:
+    """Cyclic-strip share of one rank: strip k of `strip_height` rows belongs to part k % n_parts."""
+
+    def __init__(self, n_parts, part, strip_height):
+        self.c = Strips(n_parts, part, strip_height, 0)
+
+    def local_rows(self, height):
+        return lib().ptr_strip_rows(C.byref(self.c), height)
+
+    def global_rows(self, height):
+        sh, n, part = self.c.strip_height, self.c.n_parts, self.c.part
+        rows = []
+        for k in range(part, (height + sh - 1) // sh, n):
+            rows.extend(range(k * sh, min(k * sh + sh, height)))
+        return rows
+
+
+class Stats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in
+                ("primary", "hits", "shadow_rays", "exit_tca", "exit_d2", "exit_hit", "retraced")]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class PtrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ptr error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libptr_hip.so; raises loudly if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `make -C path-tracer_amd/csrc` "
+                              "(or __graft_entry__.build()); there is no CPU fallback")
+        # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64.so.7.  If torch
+        # is going to be used in this process (bench.py, tests that hand us torch device memory) it
+        # must be loaded first so that libptr_hip.so binds to the same runtime instance; two
+        # instances cannot both own the GPU ("No HIP GPUs are available").
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = C.CDLL(LIB_PATH)
+        vp, dp, fp = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float)
+        L.ptr_abi_version.restype = C.c_int
+        L.ptr_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.ptr_destroy.argtypes = [vp]
+        L.ptr_destroy.restype = None
+        L.ptr_last_error.argtypes = [vp]
+        L.ptr_last_error.restype = C.c_char_p
+        L.ptr_set_scene.argtypes = [vp, fp, C.c_int]
+        L.ptr_set_scene_f64.argtypes = [vp, dp, C.c_int]
+        L.ptr_set_scene_sequence_f64.argtypes = [vp, dp, C.c_int, C.c_int]
+        L.ptr_set_background.argtypes = [vp, fp]
+        L.ptr_set_background_f64.argtypes = [vp, dp]
+        L.ptr_set_camera.argtypes = [vp, C.POINTER(Camera)]
+        L.ptr_render.argtypes = [vp, C.POINTER(Params), C.POINTER(C.c_uint32), fp]
+        L.ptr_render_device.argtypes = [vp, C.POINTER(Params), C.c_int, C.c_int, vp, vp, vp]
+        L.ptr_render_strips_device.argtypes = [vp, C.POINTER(Params), C.POINTER(Strips), C.c_int, C.c_int,
+                                               vp, vp, C.c_uint64, vp]
+        L.ptr_strip_rows.argtypes = [C.POINTER(Strips), C.c_int]
+        L.ptr_sync.argtypes = [vp]
+        L.ptr_trace_batch.argtypes = [vp, fp, C.c_int, C.POINTER(C.c_uint8), fp, fp]
+        L.ptr_trace_batch_f64.argtypes = [vp, dp, dp, C.c_int, dp, C.POINTER(C.c_int32), dp, dp]
+        L.ptr_get_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.ptr_get_kernel_ms.argtypes = [vp, fp, fp]
+        _lib = L
+    return _lib
+
+
+def scene_to_soa(elements):
+    """Serialized spheres (the reference's Sphere.serialize wire format, RT/src/Sphere.js:53-69)
+    -> (12, n) float64 planes: cx cy cz radius sr sg sb reflection transparency er eg eb."""
+    n = len(elements)
+    soa = np.zeros((12, n), dtype=np.float64)
+    for i, e in enumerate(elements):
+        m = e["material"]
+        soa[0:3, i] = e["center"]
+        soa[3, i] = e["radius"]
+        soa[4:7, i] = m["surfaceColor"]
+        soa[7, i] = m["reflection"]
+        soa[8, i] = m["transparency"]
+        soa[9:12, i] = m["emissionColor"]
+    return np.ascontiguousarray(soa)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Renderer:
+    """One ptr_ctx.  Mirrors `new RayTracer(backgroundColor, scene)` + `.render(...)`."""
+
+    def __init__(self, device=0):
+        self._L = lib()
+        h = C.c_void_p()
+        rc = self._L.ptr_create(device, C.byref(h))
+        if rc != OK:
+            raise PtrError(rc, self._L.ptr_last_error(None).decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ptr_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != OK:
+            raise PtrError(rc, self._L.ptr_last_error(self._h).decode())
+
+    # ---- scene
+    def set_scene(self, soa):
+        soa = np.ascontiguousarray(soa, dtype=np.float64)
+        if soa.ndim == 2:
+            assert soa.shape[0] == 12
+            self._check(self._L.ptr_set_scene_f64(self._h, _dp(soa), soa.shape[1]))
+        else:
+            assert soa.ndim == 3 and soa.shape[1] == 12     # (frames, 12, n)
+            self._check(self._L.ptr_set_scene_sequence_f64(self._h, _dp(soa), soa.shape[2], soa.shape[0]))
+
+    def set_scene_f32(self, soa):
+        soa = np.ascontiguousarray(soa, dtype=np.float32)
+        self._check(self._L.ptr_set_scene(self._h, soa.ctypes.data_as(C.POINTER(C.c_float)), soa.shape[1]))
+
+    def set_elements(self, elements):
+        self.set_scene(scene_to_soa(elements))
+
+    def set_background(self, rgb):
+        rgb = np.ascontiguousarray(rgb, dtype=np.float64)
+        self._check(self._L.ptr_set_background_f64(self._h, _dp(rgb)))
+
+    def set_camera(self, origin=None, right=(1, 0, 0), up=(0, 1, 0), forward=(0, 0, -1), tan_half_fov=None):
+        if origin is None:
+            self._check(self._L.ptr_set_camera(self._h, None))
+            return
+        import math
+        cam = Camera()
+        cam.origin[:] = origin
+        cam.right[:] = right
+        cam.up[:] = up
+        cam.forward[:] = forward
+        cam.tan_half_fov = tan_half_fov if tan_half_fov is not None else math.tan(math.pi * 0.5 * 30 / 180)
+        self._check(self._L.ptr_set_camera(self._h, C.byref(cam)))
+
+    # ---- render
+    @staticmethod
+    def params(width, height, start_y=0, scan_height=None, flags=0, max_depth=0, spp=1, seed=0):
+        return Params(width, height, start_y, height if scan_height is None else scan_height,
+                      max_depth, spp, seed, flags)
+
+    def render(self, width, height, start_y=0, scan_height=None, flags=QUIRK_ROW_SHIFT, want_f32=False):
+        p = self.params(width, height, start_y, scan_height, flags)
+        out = np.empty(p.width * p.scan_height, dtype=np.uint32)
+        f32 = np.empty((p.scan_height, p.width, 4), dtype=np.float32) if want_f32 else None
+        self._check(self._L.ptr_render(self._h, C.byref(p), out.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                       f32.ctypes.data_as(C.POINTER(C.c_float)) if want_f32 else None))
+        return (out, f32) if want_f32 else out
+
+    def render_device(self, p, first_frame, n_frames, d_rgba8, d_rgba32f=None, stream=None):
+        """d_rgba8 / d_rgba32f: device addresses (ints, e.g. tensor.data_ptr()); enqueue only."""
+        self._check(self._L.ptr_render_device(self._h, C.byref(p), first_frame, n_frames,
+                                              C.c_void_p(d_rgba8),
+                                              C.c_void_p(d_rgba32f) if d_rgba32f else None,
+                                              C.c_void_p(stream) if stream else None))
+
+    def render_strips_device(self, p, part, first_frame, n_frames, d_rgba8, d_rgba32f=None, stream=None,
+                             frame_stride_px=0):
+        self._check(self._L.ptr_render_strips_device(
+            self._h, C.byref(p), C.byref(part.c), first_frame, n_frames, C.c_void_p(d_rgba8),
+            C.c_void_p(d_rgba32f) if d_rgba32f else None, frame_stride_px,
+            C.c_void_p(stream) if stream else None))
+
+    def sync(self):
+        self._check(self._L.ptr_sync(self._h))
+
+    # ---- single rays
+    def trace_batch_f64(self, dirs, origins=None, want_hit=False):
+        dirs = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
+        n = dirs.shape[0]
+        if origins is not None:
+            origins = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
+            assert origins.shape[0] == n
+        rgb = np.empty((n, 3), dtype=np.float64)
+        el = np.empty(n, dtype=np.int32)
+        hit = np.empty((n, 3), dtype=np.float64)
+        nrm = np.empty((n, 3), dtype=np.float64)
+        self._check(self._L.ptr_trace_batch_f64(
+            self._h, _dp(origins) if origins is not None else None, _dp(dirs), n, _dp(rgb),
+            el.ctypes.data_as(C.POINTER(C.c_int32)), _dp(hit), _dp(nrm)))
+        return (rgb, el, hit, nrm) if want_hit else rgb
+
+    def trace_batch(self, dirs, want_hit=False):
+        dirs = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        n = dirs.shape[0]
+        rgb = np.empty((n, 3), dtype=np.uint8)
+        hit = np.empty((n, 3), dtype=np.float32)
+        nrm = np.empty((n, 3), dtype=np.float32)
+        fp = C.POINTER(C.c_float)
+        self._check(self._L.ptr_trace_batch(self._h, dirs.ctypes.data_as(fp), n,
+                                            rgb.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                            hit.ctypes.data_as(fp) if want_hit else None,
+                                            nrm.ctypes.data_as(fp) if want_hit else None))
+        return (rgb, hit, nrm) if want_hit else rgb
+
+    def kernel_ms(self):
+        a, b = C.c_float(), C.c_float()
+        self._check(self._L.ptr_get_kernel_ms(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def stats(self):
+        s = Stats()
+        self._check(self._L.ptr_get_stats(self._h, C.byref(s)))
+        return s.as_dict()
