@@ -31,10 +31,11 @@ struct DeviceBuffer {
 };
 
 // layout of ptr_ctx::words (device): two queue counters on lines of their own, then the stats
+constexpr size_t WORDS_COUNTERS  = (size_t)PTR_MAX_QUEUES * PTR_COUNTER_STRIDE * sizeof(uint32_t);
 constexpr size_t WORDS_COUNTER_A = 0;
-constexpr size_t WORDS_COUNTER_B = 256;
-constexpr size_t WORDS_STATS     = 512;     // 8 x uint64
-constexpr size_t WORDS_BYTES     = 768;
+constexpr size_t WORDS_COUNTER_B = WORDS_COUNTERS;
+constexpr size_t WORDS_STATS     = 2 * WORDS_COUNTERS;     // 8 x uint64
+constexpr size_t WORDS_BYTES     = WORDS_STATS + 256;
 
 }  // namespace
 
@@ -121,6 +122,7 @@ BlockLayout block_layout(int n)
     size_t o = sizeof(FrameHeader);
     L.off_g64 = (uint32_t)o;    o += align_up(sizeof(SphereG64) * (size_t)n, 16);
     L.off_m64 = (uint32_t)o;    o += align_up(sizeof(SphereM64) * (size_t)n, 16);
+    o = align_up(o, 64);
     L.off_p32 = (uint32_t)o;    o += align_up(sizeof(SphereP32) * (size_t)n, 16);
     L.off_m32 = (uint32_t)o;    o += align_up(sizeof(SphereM32) * (size_t)n, 16);
     L.off_lights = (uint32_t)o; o += align_up(sizeof(int32_t) * (size_t)(n > 0 ? n : 1), 16);
@@ -272,7 +274,13 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
     std::memset(&a, 0, sizeof a);
     a.scenes = static_cast<const unsigned char*>(c->scenes.ptr);
     a.frame_stride = c->frame_stride;
+    {
+        const BlockLayout L = block_layout(c->n_spheres);
+        a.off_p32 = L.off_p32; a.off_m32 = L.off_m32; a.off_lights = L.off_lights;
+        a.n = c->n_spheres;
+    }
     a.first_frame = first_frame;
+    a.n_frames = n_frames;
     a.width = p->width; a.height = p->height; a.start_y = p->start_y; a.scan_height = p->scan_height;
     a.flags = p->flags;
     a.strip_h = strips ? strips->strip_height : 1;
@@ -311,7 +319,6 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
     }
 
     if (exact) {
-        c->words_dirty |= stats;      // cheap: next call clears everything again
         HIP_TRY(c, launch_render_exact(a, n_frames, stats, s));
         if (timing) { HIP_TRY(c, hipEventRecord(c->ev[1], s)); c->timed_kernels = 1; }
         return PTR_OK;
@@ -321,23 +328,27 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
         if (timing) { HIP_TRY(c, hipEventRecord(c->ev[1], s)); c->timed_kernels = 1; }
         return PTR_OK;
     }
-    // hybrid: float32 kernel fills the queue, float64 kernel drains it
-    const uint64_t px = (uint64_t)p->width * (uint64_t)p->scan_height * (uint64_t)n_frames;
-    PTR_TRY(grow(c, c->queue, (size_t)px * sizeof(uint32_t)));
+    // hybrid: float32 kernel fills the sub-queues, float64 kernel drains them
+    const uint64_t n_blocks = (uint64_t)((p->width + PTR_TILE_W - 1) / PTR_TILE_W) *
+                              (uint64_t)((p->scan_height + PTR_TILE_H - 1) / PTR_TILE_H) * (uint64_t)n_frames;
+    uint64_t n_queues = n_blocks / 4;
+    if (n_queues < 1) n_queues = 1;
+    if (n_queues > PTR_MAX_QUEUES) n_queues = PTR_MAX_QUEUES;
+    // a workgroup can queue at most PTR_BLOCK pixels; sub-queue s serves the workgroups b with b % n_queues == s
+    const uint64_t sub_capacity = (n_blocks + n_queues - 1) / n_queues * PTR_BLOCK;
+    PTR_TRY(grow(c, c->queue, (size_t)(n_queues * sub_capacity) * sizeof(uint32_t)));
     const bool odd = (c->hybrid_calls & 1u) != 0;
     a.queue = static_cast<uint32_t*>(c->queue.ptr);
-    a.queue_capacity = (uint32_t)px;
+    a.queue_capacity = (uint32_t)sub_capacity;
+    a.n_queues = (uint32_t)n_queues;
     a.counter = reinterpret_cast<uint32_t*>(words + (odd ? WORDS_COUNTER_B : WORDS_COUNTER_A));
     a.counter_next = reinterpret_cast<uint32_t*>(words + (odd ? WORDS_COUNTER_A : WORDS_COUNTER_B));
     c->hybrid_calls++;
+    HIP_TRY(c, hipMemsetAsync(words + WORDS_STATS, 0, 256, s));
     hipError_t e = launch_render_fast(a, n_frames, true, s);
     if (e == hipSuccess && timing) e = hipEventRecord(c->ev[1], s);
     if (e == hipSuccess) {
-        // enough lanes to drain a queue of a few percent of the pixels in one or two sweeps
-        uint64_t blocks = (px / 64 + PTR_BLOCK - 1) / PTR_BLOCK;
-        if (blocks < 1) blocks = 1;
-        if (blocks > 2048) blocks = 2048;
-        e = launch_retrace_exact(a, (int)blocks, s);
+        e = launch_retrace_exact(a, s);
         if (e == hipSuccess && timing) { e = hipEventRecord(c->ev[2], s); c->timed_kernels = 2; }
     }
     if (e != hipSuccess) {

@@ -14,6 +14,8 @@
 #define PTR_TILE_W 32         // workgroup tile: 4 waves side by side, each an 8x8 pixel tile
 #define PTR_TILE_H 8
 #define PTR_BLOCK  256
+#define PTR_MAX_QUEUES 1024       // sub-queues of the hybrid mode's re-trace queue
+#define PTR_COUNTER_STRIDE 16     // uint32 words between two sub-queue counters (64 B)
 
 namespace ptr {
 
@@ -39,21 +41,20 @@ struct alignas(16) SphereM64 { double sr, sg, sb, er, eg, eb; };    // exact mat
 // Read with wave-uniform indices -> scalar loads (s_load_dwordx8 / x4 per sphere); the
 // winner's record is gathered per lane once per pixel.
 // eps below is the float32 unit roundoff 2^-24; "scale" = max(|l|^2, r^2).
-struct alignas(16) SphereP32 {
-    // group 0: primary hit test
+struct alignas(64) SphereP32 {
+    // group 0+1 (one s_load_dwordx8): primary hit test and shadow test
     float lx, ly, lz;     // l = C - origin
     float cc;             // |l|^2 - r^2   (sign: origin outside (+) / inside (-) the sphere)
-    // group 1: primary hit test, "not sure" bands
     float md;             // bound on the error of disc = b^2 - cc          (24 eps scale)
     float kb;             // md / eb, eb = bound on the error of b = l.d    (10 eps sqrt(scale))
-    float sgn;            // -1: outside, nearest root is b - thc;  +1: inside, root is b + thc
-    float unsure;         // 1.0f: |cc| too small to trust its sign -> any hit on it is re-traced
-    // group 2: ordering band, shadow test
-    float hmd;            // md / 2:  |dt| <= hmd / thc + eb
-    float eb;
     float r2;             // radius^2
     float lnorm;          // |l|
-    // group 3: winner refinement
+    // group 2: only when some lane of the wave hits the sphere
+    float sgn;            // -1: outside, nearest root is b - thc;  +1: inside, root is b + thc
+    float unsure;         // 1.0f: |cc| too small to trust its sign -> any hit on it is re-traced
+    float hmd;            // md / 2:  |dt| <= hmd / thc + eb
+    float eb;
+    // group 3: winner refinement (per-lane gather)
     float inv_r;          // 1 / radius
     float hed;            // half the error bound of disc' = r^2 - |l x d|^2  (10 eps r |l| + 2 eps r^2)
     float pad0, pad1;
@@ -102,7 +103,9 @@ struct CameraF32 {
 struct RenderArgs {
     const unsigned char* scenes;     // frame blocks, frame_stride bytes apart
     uint64_t  frame_stride;
-    int32_t   first_frame;
+    uint32_t  off_p32, off_m32, off_lights;   // byte offsets inside a frame block (same for every frame)
+    int32_t   n;                     // elements per frame
+    int32_t   first_frame, n_frames;
     int32_t   width, height, start_y, scan_height;
     uint32_t  flags;                 // PTR_QUIRK_ROW_SHIFT etc. (include/ptr.h)
     int32_t   strip_h, n_parts, part; // cyclic strips: local row r is image row global_y(r); n_parts 1 = band
@@ -111,10 +114,11 @@ struct RenderArgs {
     CameraF32  camf;
     uint32_t* out8;                  // n_frames * width * scan_height
     float*    out32f;                // nullable, n_frames * width * scan_height * 4
-    uint32_t* queue;                 // hybrid: global pixel ids to re-trace
-    uint32_t* counter;               // hybrid: queue fill (this call's counter word)
-    uint32_t* counter_next;          // hybrid: the other counter word, zeroed for the next call
-    uint32_t  queue_capacity;
+    uint32_t* queue;                 // hybrid: n_queues sub-queues of global pixel ids to re-trace
+    uint32_t* counter;               // hybrid: sub-queue fills (this call's set), PTR_COUNTER_STRIDE apart
+    uint32_t* counter_next;          // hybrid: the other set, zeroed by the re-trace for the next call
+    uint32_t  queue_capacity;        // entries per sub-queue
+    uint32_t  n_queues;
     unsigned long long* stats;       // nullable; 8 words, see ptr_stats
 };
 

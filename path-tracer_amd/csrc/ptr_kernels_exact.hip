@@ -169,15 +169,22 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_exact_kernel(RenderArgs a)
 }
 
 // hybrid mode, second kernel: re-trace the pixels the float32 kernel was not sure about.
-// Fixed grid, grid-stride over the queue; the fill count is read from device memory, so the
-// host never synchronises between the two kernels.
+// One workgroup per sub-queue; the fill counts are read from device memory, so the host never
+// synchronises between the two kernels.
 __global__ void __launch_bounds__(PTR_BLOCK) retrace_exact_kernel(RenderArgs a)
 {
-    const uint32_t fill = *a.counter;
+    // The grid always has PTR_MAX_QUEUES workgroups: every counter of the OTHER set is zeroed for the
+    // next call (which may use more sub-queues than this one); workgroups past n_queues do only that.
+    const uint32_t sub = blockIdx.x;
+    if (threadIdx.x == 0) a.counter_next[sub * PTR_COUNTER_STRIDE] = 0u;
+    if (sub >= a.n_queues) return;
+    const uint32_t fill = a.counter[sub * PTR_COUNTER_STRIDE];
     const uint32_t count = fill < a.queue_capacity ? fill : a.queue_capacity;
+    const uint32_t* queue = a.queue + (uint64_t)sub * a.queue_capacity;
     const uint64_t frame_px = (uint64_t)a.width * (uint64_t)a.scan_height;
-    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < count; q += gridDim.x * blockDim.x) {
-        const uint64_t gid = a.queue[q];
+    for (uint32_t q = threadIdx.x; q < count; q += blockDim.x) {
+        const uint64_t gid = queue[q];
+        if (gid >= frame_px * (uint64_t)a.n_frames) continue;      // never trust a queue word blindly
         const int frame = (int)(gid / frame_px);
         const uint32_t pix = (uint32_t)(gid - (uint64_t)frame * frame_px);
         const int row = (int)(pix / (uint32_t)a.width), x = (int)(pix - (uint32_t)row * a.width);
@@ -193,10 +200,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) retrace_exact_kernel(RenderArgs a)
             p[0] = (float)c.x; p[1] = (float)c.y; p[2] = (float)c.z; p[3] = 1.0f;
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        *a.counter_next = 0u;                          // ready for the next call on this stream
-        if (a.stats) a.stats[ST_RETRACED] = count;
-    }
+    if (threadIdx.x == 0 && a.stats) atomicAdd(&a.stats[ST_RETRACED], (unsigned long long)count);
 }
 
 __global__ void __launch_bounds__(PTR_BLOCK) trace_batch_exact_kernel(TraceArgs a)
@@ -224,9 +228,9 @@ hipError_t launch_render_exact(const RenderArgs& a, int n_frames, bool stats, hi
     return hipGetLastError();
 }
 
-hipError_t launch_retrace_exact(const RenderArgs& a, int blocks, hipStream_t s)
+hipError_t launch_retrace_exact(const RenderArgs& a, hipStream_t s)
 {
-    hipLaunchKernelGGL(retrace_exact_kernel, dim3(blocks), dim3(PTR_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(retrace_exact_kernel, dim3(PTR_MAX_QUEUES), dim3(PTR_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 

@@ -30,6 +30,25 @@ constexpr float FAR_UNSURE = 9.0e7f;     // anything this close to the 1e8 far c
 
 struct F3 { float x, y, z; };
 
+// Scene data is read-only for the whole launch: typing it as the constant address space makes
+// every wave-uniform read a scalar load (s_load_dwordx4/x8 into SGPRs, batched by the unroller)
+// whatever stores the kernel has issued before.
+#define PTR_CONST __attribute__((address_space(4)))
+typedef const SphereP32 PTR_CONST* ConstP32;
+typedef const SphereM32 PTR_CONST* ConstM32;
+typedef const FrameHeader PTR_CONST* ConstHeader;
+typedef const int32_t PTR_CONST* ConstI32;
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef const f4 PTR_CONST* ConstF4;
+
+// the 12 leading floats of a SphereP32 record, fetched with scalar loads one sphere ahead of use
+struct P32Q { f4 g0, g1, g2; };
+__device__ __forceinline__ P32Q load_p32(ConstP32 base, int i)
+{
+    const ConstF4 q = (ConstF4)(base + i);
+    return P32Q{q[0], q[1], q[2]};
+}
+
 __device__ __forceinline__ float dot3(F3 a, F3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -39,14 +58,16 @@ enum : unsigned { WHY_PRIMARY = 1, WHY_CC = 2, WHY_ORDER = 4, WHY_FAR = 8, WHY_S
 
 template <bool DBG> struct Unsure;
 template <> struct Unsure<false> {
-    bool any = false;
-    __device__ __forceinline__ void add(bool c, unsigned) { any |= c; }
+    // kept as a wave-wide lane mask in SGPRs: accumulating costs scalar ORs, no vector ALU
+    unsigned long long mask = 0ull;
+    __device__ __forceinline__ void add(bool c, unsigned) { mask |= __builtin_amdgcn_ballot_w64(c); }
+    __device__ __forceinline__ bool any() const { return __builtin_amdgcn_inverse_ballot_w64(mask); }
     __device__ __forceinline__ unsigned why() const { return 0u; }
 };
 template <> struct Unsure<true> {
-    bool any = false;
     unsigned bits = 0u;
-    __device__ __forceinline__ void add(bool c, unsigned bit) { any |= c; bits |= c ? bit : 0u; }
+    __device__ __forceinline__ void add(bool c, unsigned bit) { bits |= c ? bit : 0u; }
+    __device__ __forceinline__ bool any() const { return bits != 0u; }
     __device__ __forceinline__ unsigned why() const { return bits; }
 };
 
@@ -72,8 +93,13 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
     }
 
     const unsigned char* block = a.scenes + (uint64_t)(a.first_frame + frame) * a.frame_stride;
-    const FrameView fv = frame_view(block);
-    const int n = fv.h->n;
+    const ConstHeader hdr = (ConstHeader)(uintptr_t)block;
+    const ConstP32 cp32 = (ConstP32)(uintptr_t)(block + a.off_p32);        // uniform reads
+    const ConstM32 cm32 = (ConstM32)(uintptr_t)(block + a.off_m32);
+    const ConstI32 clights = (ConstI32)(uintptr_t)(block + a.off_lights);
+    const SphereP32* gp32 = reinterpret_cast<const SphereP32*>(block + a.off_p32);   // per-lane gathers
+    const SphereM32* gm32 = reinterpret_cast<const SphereM32*>(block + a.off_m32);
+    const int n = a.n;
 
     // ---- camera ray (RayTracer.js:171-174) ------------------------------------------------
     const float xx = fmaf((float)x + 0.5f, a.camf.sx, a.camf.ox);
@@ -96,42 +122,57 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
     Unsure<DBG> unsure;
     float tnear = 3.0e38f, t2 = 3.0e38f, etmax = 0.0f;
     int idx = -1;
-    for (int i = 0; i < n; i++) {
-        const SphereP32* ps = fv.p32 + i;              // wave-uniform -> scalar loads
-        const float b = fmaf(ps->lz, d.z, fmaf(ps->ly, d.y, ps->lx * d.x));
-        const float disc = fmaf(b, b, -ps->cc);
-        const float m = fminf(b * ps->kb, disc);       // hit <=> b >= 0 && disc >= 0 <=> m >= 0
-        unsure.add(fabsf(m) <= ps->md, WHY_PRIMARY);
+    auto primary = [&](const P32Q& q, int i) {
+        const float b = fmaf(q.g0.z, d.z, fmaf(q.g0.y, d.y, q.g0.x * d.x));
+        const float disc = fmaf(b, b, -q.g0.w);
+        const float m = fminf(b * q.g1.y, disc);       // hit <=> b >= 0 && disc >= 0 <=> m >= 0
+        // NB: the lane masks behind `unsure` are wave-uniform values; they may only be updated in
+        // wave-uniform control flow (never inside an exec-masked block like the one below).
+        unsure.add(fabsf(m) <= q.g1.x, WHY_PRIMARY);
+        unsure.add((m >= 0.0f) & (q.g2.y != 0.0f), WHY_CC);
         if (m >= 0.0f) {                               // skipped by the wave when no lane hits
             const float s = rsq(disc);
-            const float t = fmaf(ps->sgn, disc * s, b);   // t0, or t1 when t0 < 0 (RayTracer.js:32-34)
-            etmax = fmaxf(etmax, fmaf(ps->hmd, s, ps->eb));
+            const float t = fmaf(q.g2.x, disc * s, b);    // t0, or t1 when t0 < 0 (RayTracer.js:32-34)
+            etmax = fmaxf(etmax, fmaf(q.g2.z, s, q.g2.w));
             t2 = __builtin_amdgcn_fmed3f(tnear, t2, t);   // second smallest so far
             idx = t < tnear ? i : idx;
             tnear = fminf(tnear, t);
-            unsure.add(ps->unsure != 0.0f, WHY_CC);
+        }
+    };
+    // two record buffers in SGPRs, each loaded one sphere ahead of its use (hides the scalar-load
+    // latency); n == 0 reads the zeroed padding of the block and loops zero times
+    {
+        P32Q A = load_p32(cp32, 0);
+        for (int i = 0; i < n; i += 2) {
+            const P32Q B = load_p32(cp32, i + 1 < n ? i + 1 : i);
+            primary(A, i);
+            if (i + 1 >= n) break;
+            A = load_p32(cp32, i + 2 < n ? i + 2 : i + 1);
+            primary(B, i + 1);
         }
     }
     // nearest-vs-second ordering, far clip (t < 1e8, RayTracer.js:19,36)
     unsure.add((t2 - tnear <= 2.0f * etmax) & (idx >= 0), WHY_ORDER);
     unsure.add((tnear >= FAR_UNSURE) & (idx >= 0), WHY_FAR);
 
-    float cr, cg, cb;          // unclamped colour
-    uint32_t packed;
-    if (idx < 0) {
-        // miss: the background, bit-exact by construction (RayTracer.js:43-46)
-        cr = fv.h->bg32[0]; cg = fv.h->bg32[1]; cb = fv.h->bg32[2];
-        packed = fv.h->bg_packed;
-    } else {
+    // miss: the background, bit-exact by construction (RayTracer.js:43-46)
+    float cr = hdr->bg32[0], cg = hdr->bg32[1], cb = hdr->bg32[2];     // unclamped colour
+    uint32_t packed = hdr->bg_packed;
+    const bool valid = idx >= 0;
+    // Wave-uniform branch: taken when any lane hit something; lanes that missed run along on
+    // sphere 0 with every flag and result masked by `valid` (keeps all control flow below scalar).
+    if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
+        idx = valid ? idx : 0;
         // ---- winner, recomputed accurately (per-lane gather of its record) ---------------------
         // disc' = r^2 - |l x d|^2 has no cancellation between |l|^2 and b^2, and the nearest root
         // is taken in its cancellation-free form t = cc / (b + thc).
-        const float4 g0 = *reinterpret_cast<const float4*>(&fv.p32[idx].lx);    // lx ly lz cc
-        const float4 g2 = *reinterpret_cast<const float4*>(&fv.p32[idx].hmd);   // hmd eb r2 lnorm
-        const float2 g3 = *reinterpret_cast<const float2*>(&fv.p32[idx].inv_r); // inv_r hed
-        const SphereM32 mw = fv.m32[idx];
+        const float4 g0 = *reinterpret_cast<const float4*>(&gp32[idx].lx);    // lx ly lz cc
+        const float2 g1 = *reinterpret_cast<const float2*>(&gp32[idx].r2);    // r2 lnorm
+        const float eb_w = gp32[idx].eb;
+        const float2 g3 = *reinterpret_cast<const float2*>(&gp32[idx].inv_r); // inv_r hed
+        const SphereM32 mw = gm32[idx];
         const F3 lw{g0.x, g0.y, g0.z};
-        const float cc_w = g0.w, eb_w = g2.y, r2_w = g2.z, inv_r = g3.x, hed_w = g3.y;
+        const float cc_w = g0.w, r2_w = g1.x, lnorm_w = g1.y, inv_r = g3.x, hed_w = g3.y;
         const float b_w = dot3(lw, d);
         const F3 cr3{fmaf(lw.y, d.z, -lw.z * d.y), fmaf(lw.z, d.x, -lw.x * d.z), fmaf(lw.x, d.y, -lw.y * d.x)};
         const float disc_w = fmaxf(r2_w - dot3(cr3, cr3), 1e-30f);
@@ -152,46 +193,58 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
             const float sg = outside ? inv : -inv;     // inside: d.N > 0 -> revert (RayTracer.js:54-58)
             N.x *= sg; N.y *= sg; N.z *= sg;
         }
-        const float eN = fmaf(eP + EPS * (g2.w + t), inv_r, 3.0f * EPS);   // |error of N|
+        const float eN = fmaf(eP + EPS * (lnorm_w + t), inv_r, 3.0f * EPS);   // |error of N|
         const F3 so{fmaf(N.x, (float)PTR_BIAS, P.x), fmaf(N.y, (float)PTR_BIAS, P.y), fmaf(N.z, (float)PTR_BIAS, P.z)};
 
         // ---- direct light + binary shadow (RayTracer.js:61-91) ---------------------------------
         float ar = 0.0f, ag = 0.0f, ab = 0.0f;
         float wsum = 0.0f, eLmax = 0.0f;
-        const int nl = fv.h->n_lights;
+        const int nl = hdr->n_lights;
         for (int k = 0; k < nl; k++) {
-            const int i = fv.lights[k];
-            const SphereP32* pl = fv.p32 + i;
-            const SphereM32* ml = fv.m32 + i;
-            F3 L{pl->lx - P.x, pl->ly - P.y, pl->lz - P.z};
+            const int i = clights[k];
+            const P32Q pl = load_p32(cp32, i);
+            const ConstM32 ml = cm32 + i;
+            F3 L{pl.g0.x - P.x, pl.g0.y - P.y, pl.g0.z - P.z};
             const float invl = rsq(dot3(L, L));
             L.x *= invl; L.y *= invl; L.z *= invl;
-            const float eL = fmaf(fmaf(EPS, pl->lnorm + t, eP), invl, 3.0f * EPS);   // |error of L|
+            const float eL = fmaf(fmaf(EPS, pl.g1.w + t, eP), invl, 3.0f * EPS);   // |error of L|
             const float ratio = dot3(N, L);
-            bool open = ratio > 0.0f;                  // lanes that still need a shadow verdict
-            bool maybe = false, blocked32 = false;
             const float kL = fmaf(2.0f, eL, 10.0f * EPS);
-            for (int j = 0; j < n; j++) {
-                if (j == i) continue;
-                if (__builtin_amdgcn_ballot_w64(open) == 0ull) break;
-                const SphereP32* pj = fv.p32 + j;
-                const F3 lj{pj->lx - so.x, pj->ly - so.y, pj->lz - so.z};
+            // lane masks (SGPR pairs): lanes still needing a verdict / inside a band / blocked in float32
+            unsigned long long open_m = __builtin_amdgcn_ballot_w64((ratio > 0.0f) & valid);
+            unsigned long long maybe_m = 0ull, blocked_m = 0ull;
+            auto shadow = [&](const P32Q& pj) {
+                const F3 lj{pj.g0.x - so.x, pj.g0.y - so.y, pj.g0.z - so.z};
                 const float bj = dot3(lj, L);
                 const float ll = dot3(lj, lj);
-                const float disc = fmaf(bj, bj, pj->r2 - ll);
+                const float disc = fmaf(bj, bj, pj.g1.z - ll);
                 // error bounds: |lj| <= A, d(lj) <= dlj, d(bj) <= ebj, d(disc) <= band
-                const float A = pj->lnorm + t + 2.0e-4f;
+                const float A = pj.g1.w + t + 2.0e-4f;
                 const float dlj = fmaf(EPS, A, eP);
                 const float band = fmaf(ll, kL, 4.0f * A * dlj);
                 const float ebj = fmaf(A, eL + 3.0f * EPS, dlj);
-                const bool certain = (bj > ebj) & (disc > band);   // any-hit for sure (RayTracer.js:77-81)
-                maybe |= open & (bj >= -ebj) & (disc >= -band) & !certain;
-                blocked32 |= open & (bj >= 0.0f) & (disc >= 0.0f);  // the float32 verdict
-                open &= !certain;
+                // certain any-hit (RayTracer.js:77-81) / possible hit
+                const unsigned long long certain = __builtin_amdgcn_ballot_w64((bj > ebj) & (disc > band));
+                const unsigned long long possible = __builtin_amdgcn_ballot_w64((bj >= -ebj) & (disc >= -band));
+                maybe_m |= open_m & possible & ~certain;
+                if constexpr (!HYBRID)                 // the float32 verdict only shows in f32-only output
+                    blocked_m |= open_m & __builtin_amdgcn_ballot_w64((bj >= 0.0f) & (disc >= 0.0f));
+                open_m &= ~certain;
+            };
+            {
+                P32Q A = load_p32(cp32, 0);
+                for (int j = 0; j < n; j += 2) {
+                    const P32Q B = load_p32(cp32, j + 1 < n ? j + 1 : j);
+                    if (open_m == 0ull) break;
+                    if (j != i) shadow(A);             // the light itself never blocks (RayTracer.js:76)
+                    if (j + 1 >= n) break;
+                    A = load_p32(cp32, j + 2 < n ? j + 2 : j + 1);
+                    if (j + 1 != i) shadow(B);
+                }
             }
             // A "maybe" only matters if no certain hit blocks the light anyway.
-            unsure.add(open & maybe, WHY_SHADOW);
-            open &= !blocked32;
+            unsure.add(__builtin_amdgcn_inverse_ballot_w64(open_m & maybe_m), WHY_SHADOW);
+            const bool open = __builtin_amdgcn_inverse_ballot_w64(open_m & ~blocked_m);
             if (open) {
                 ar = fmaf(mw.sr * ml->er, ratio, ar);
                 ag = fmaf(mw.sg * ml->eg, ratio, ag);
@@ -200,19 +253,23 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
                 eLmax = fmaxf(eLmax, eL);
             }
         }
-        cr = ar + mw.er; cg = ag + mw.eg; cb = ab + mw.eb;   // RayTracer.js:93
+        const float hr = ar + mw.er, hg = ag + mw.eg, hb = ab + mw.eb;   // RayTracer.js:93
 
         // ---- clamp, round, pack (RayTracer.js:179-192) with a rounding band ------------------
         // |error of N.L| <= eN + eL (+ rounding of the dot and of the sums, 8 eps)
         const float band = 255.0f * fmaf(mw.scmax * wsum, eN + eLmax + 8.0f * EPS, 4.0f * EPS * mw.emax) + 2e-5f;
-        const float vr = fminf(cr, 1.0f) * 255.0f, vg = fminf(cg, 1.0f) * 255.0f, vb = fminf(cb, 1.0f) * 255.0f;
+        const float vr = fminf(hr, 1.0f) * 255.0f, vg = fminf(hg, 1.0f) * 255.0f, vb = fminf(hb, 1.0f) * 255.0f;
         const float fr = floorf(vr), fg = floorf(vg), fb = floorf(vb);
         const float qr = vr - fr, qg = vg - fg, qb = vb - fb;
-        unsure.add((fabsf(qr - 0.5f) <= band) | (fabsf(qg - 0.5f) <= band) | (fabsf(qb - 0.5f) <= band), WHY_ROUND);
+        const bool near_half = (fabsf(qr - 0.5f) <= band) | (fabsf(qg - 0.5f) <= band) | (fabsf(qb - 0.5f) <= band);
+        unsure.add(near_half & valid, WHY_ROUND);
         const uint32_t r8 = (uint32_t)(qr >= 0.5f ? fr + 1.0f : fr);
         const uint32_t g8 = (uint32_t)(qg >= 0.5f ? fg + 1.0f : fg);
         const uint32_t b8 = (uint32_t)(qb >= 0.5f ? fb + 1.0f : fb);
-        packed = (255u << 24) | (b8 << 16) | (g8 << 8) | r8;
+        if (valid) {
+            packed = (255u << 24) | (b8 << 16) | (g8 << 8) | r8;
+            cr = hr; cg = hg; cb = hb;
+        }
     }
 
     if constexpr (DBG) packed = unsure.why();
@@ -222,10 +279,14 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
         *p = make_float4(cr, cg, cb, 1.0f);
     }
     if constexpr (HYBRID) {
-        if (unsure.any) {
-            const uint32_t q = atomicAdd(a.counter, 1u);
+        if (unsure.any()) {
+            // one counter word would saturate (~88 returning atomics/us chip-wide): the queue is cut
+            // into n_queues sub-queues, each with its own counter line, chosen by workgroup
+            const uint32_t bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            const uint32_t sub = bid % a.n_queues;
+            const uint32_t q = atomicAdd(a.counter + sub * PTR_COUNTER_STRIDE, 1u);
             if (q < a.queue_capacity)
-                a.queue[q] = (uint32_t)(frame * frame_px + (uint64_t)a.width * row + x);
+                a.queue[(uint64_t)sub * a.queue_capacity + q] = (uint32_t)(frame * frame_px + (uint64_t)a.width * row + x);
         }
     }
 }

@@ -49,7 +49,13 @@ for y, x in list(zip(ys, xs))[:4000]:
 print("shadow-flagged pixels by (hit element, differs):", sorted(cnt.items()))
 sel = diff & ((whym & 16) != 0)
 ys, xs = np.nonzero(sel)
-print("differing shadow-flagged pixels: rows", ys.min(), ys.max(), "cols", xs.min(), xs.max())
+if ys.size: print("differing shadow-flagged pixels: rows", ys.min(), ys.max(), "cols", xs.min(), xs.max())
 g = got8.reshape(h, w); wv = want8.reshape(h, w)
 for y, x in list(zip(ys, xs))[:40]:
     print(y, x, hex(g[y, x]), hex(wv[y, x]), f32[y, x, :3], want[y, x])
+hy = r.render(w, h, flags=0)
+bad = np.flatnonzero(hy != want8)
+print("HYBRID differs in", bad.size, "pixels; of these flagged:", int(flag.ravel()[bad].sum()), " retraced stat:", r.stats()["retraced"])
+for i in bad[:10]:
+    yy_, xx_ = divmod(int(i), w)
+    print("  ", yy_, xx_, hex(hy[i]), hex(want8[i]), hex(got8[i]), "why", int(why[i]))
