@@ -123,7 +123,7 @@ BlockLayout block_layout(int n)
     L.off_g64 = (uint32_t)o;    o += align_up(sizeof(SphereG64) * (size_t)n, 16);
     L.off_m64 = (uint32_t)o;    o += align_up(sizeof(SphereM64) * (size_t)n, 16);
     o = align_up(o, 64);
-    L.off_p32 = (uint32_t)o;    o += align_up(sizeof(SphereP32) * (size_t)n, 16);
+    L.off_p32 = (uint32_t)o;    o += sizeof(SphereP32) * ((size_t)n + 2);   // + 2 zero records: look-ahead loads
     L.off_m32 = (uint32_t)o;    o += align_up(sizeof(SphereM32) * (size_t)n, 16);
     L.off_lights = (uint32_t)o; o += align_up(sizeof(int32_t) * (size_t)(n > 0 ? n : 1), 16);
     L.bytes = align_up(o, 256);
@@ -177,7 +177,7 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
         p.hmd = (float)(0.5 * PR_RELD * scale);
         p.eb = (float)(PR_RELB * std::sqrt(scale));
         p.r2 = (float)r2;
-        p.lnorm = (float)(lnorm * (1.0 + 2 * EPS32));
+        p.lnorm = (float)(lnorm * (1.0 + 2 * EPS32) + 2.1e-4);   // upper bound of |l| + shadow bias
         p.inv_r = (float)(1.0 / std::fmax(rad, 1e-30));
         p.hed = (float)(10.0 * EPS32 * rad * lnorm + 2.0 * EPS32 * r2);
         p32[i] = p;
@@ -329,13 +329,14 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
         return PTR_OK;
     }
     // hybrid: float32 kernel fills the sub-queues, float64 kernel drains them
+    const int rpb = fast_kernel_rows_per_block();
     const uint64_t n_blocks = (uint64_t)((p->width + PTR_TILE_W - 1) / PTR_TILE_W) *
-                              (uint64_t)((p->scan_height + PTR_TILE_H - 1) / PTR_TILE_H) * (uint64_t)n_frames;
+                              (uint64_t)((p->scan_height + rpb - 1) / rpb) * (uint64_t)n_frames;
     uint64_t n_queues = n_blocks / 4;
     if (n_queues < 1) n_queues = 1;
     if (n_queues > PTR_MAX_QUEUES) n_queues = PTR_MAX_QUEUES;
     // a workgroup can queue at most PTR_BLOCK pixels; sub-queue s serves the workgroups b with b % n_queues == s
-    const uint64_t sub_capacity = (n_blocks + n_queues - 1) / n_queues * PTR_BLOCK;
+    const uint64_t sub_capacity = (n_blocks + n_queues - 1) / n_queues * (uint64_t)(PTR_TILE_W * rpb);
     PTR_TRY(grow(c, c->queue, (size_t)(n_queues * sub_capacity) * sizeof(uint32_t)));
     const bool odd = (c->hybrid_calls & 1u) != 0;
     a.queue = static_cast<uint32_t*>(c->queue.ptr);

@@ -14,6 +14,7 @@
 #define PTR_TILE_W 32         // workgroup tile: 4 waves side by side, each an 8x8 pixel tile
 #define PTR_TILE_H 8
 #define PTR_BLOCK  256
+#define PTR_FAST_PPL 2            // pixels per lane in the float32 kernel (wave tile 8 x 16)
 #define PTR_MAX_QUEUES 1024       // sub-queues of the hybrid mode's re-trace queue
 #define PTR_COUNTER_STRIDE 16     // uint32 words between two sub-queue counters (64 B)
 

@@ -12,5 +12,6 @@ hipError_t launch_trace_batch_exact(const TraceArgs& a, hipStream_t s);
 
 // float32 with uncertainty filter (ptr_kernels_fast.hip); hybrid = queue unsure pixels
 hipError_t launch_render_fast(const RenderArgs& a, int n_frames, bool hybrid, hipStream_t s);
+int fast_kernel_rows_per_block();   // image rows one workgroup of the float32 kernel covers
 
 }  // namespace ptr
