@@ -1,0 +1,396 @@
+/*
+ * ptr_napi.c — thin N-API addon over the C ABI of include/ptr.h (libptr_hip.so).
+ *
+ * This is the binding a maintainer of raytracer-js adds to replace the canvas/worker render loop
+ * (RT/src/RayTracer.js:132-197 called from RT/examples/example1.js:65 and RT/src/RenderWorker.js:61).
+ * It holds no rendering logic: every call converts arguments and forwards to one ptr_* function.
+ * Raw node_api.h (C), N-API version <= 8, context-aware (NAPI_MODULE_INIT, no global state).
+ *
+ *   create(device)                                   -> external handle      ptr_create
+ *   destroy(h)                                                               ptr_destroy
+ *   setScene(h, Float64Array soa, n, nFrames)                                ptr_set_scene_sequence_f64
+ *   setBackground(h, r, g, b)                                                ptr_set_background_f64
+ *   setCamera(h, Float64Array(13) | null)                                    ptr_set_camera
+ *   render(h, w, height, startY, scanHeight, flags)  -> ArrayBuffer (RGBA8)  ptr_render
+ *   renderAsync(h, w, height, startY, scanHeight, flags) -> Promise<ArrayBuffer>
+ *   traceBatch(h, Float64Array origins | null, Float64Array dirs)
+ *        -> { rgb: Float64Array, element: Int32Array, hit: Float64Array, normal: Float64Array }
+ *                                                                            ptr_trace_batch_f64
+ *   stats(h) -> { primary, hits, shadowRays, exitTca, exitD2, exitHit, retraced }   ptr_get_stats
+ */
+#include <node_api.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../../include/ptr.h"
+
+#define NAPI_TRY(env, call)                                                                    \
+    do {                                                                                       \
+        if ((call) != napi_ok) {                                                               \
+            napi_throw_error((env), NULL, "N-API call failed: " #call);                        \
+            return NULL;                                                                       \
+        }                                                                                      \
+    } while (0)
+
+static napi_value throw_ptr(napi_env env, ptr_ctx *ctx, int rc)
+{
+    const char *msg = ptr_last_error(ctx);
+    const char *name = rc == PTR_ERR_INVALID ? "PTR_ERR_INVALID" : rc == PTR_ERR_NO_DEVICE ? "PTR_ERR_NO_DEVICE"
+                     : rc == PTR_ERR_HIP ? "PTR_ERR_HIP" : rc == PTR_ERR_NO_SCENE ? "PTR_ERR_NO_SCENE"
+                     : rc == PTR_ERR_UNSUPPORTED ? "PTR_ERR_UNSUPPORTED" : "PTR_ERR";
+    if (rc == PTR_ERR_INVALID) napi_throw_range_error(env, name, msg);
+    else napi_throw_error(env, name, msg);
+    return NULL;
+}
+
+static void finalize_ctx(napi_env env, void *data, void *hint)
+{
+    (void)env; (void)hint;
+    ptr_destroy((ptr_ctx *)data);          /* the GC owns handles that were never destroy()ed */
+}
+
+/* handles are napi externals whose data pointer is cleared by destroy() via a wrapper cell */
+typedef struct { ptr_ctx *ctx; } handle_cell;
+
+static void finalize_cell(napi_env env, void *data, void *hint)
+{
+    handle_cell *cell = (handle_cell *)data;
+    if (cell->ctx) finalize_ctx(env, cell->ctx, hint);
+    free(cell);
+}
+
+static ptr_ctx *get_ctx(napi_env env, napi_value v)
+{
+    handle_cell *cell = NULL;
+    if (napi_get_value_external(env, v, (void **)&cell) != napi_ok || !cell || !cell->ctx) {
+        napi_throw_type_error(env, NULL, "not a live renderer handle");
+        return NULL;
+    }
+    return cell->ctx;
+}
+
+static int get_args(napi_env env, napi_callback_info info, size_t want, napi_value *argv)
+{
+    size_t argc = want;
+    if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < want) {
+        napi_throw_type_error(env, NULL, "wrong number of arguments");
+        return 0;
+    }
+    return 1;
+}
+
+static int get_i32(napi_env env, napi_value v, int32_t *out)
+{
+    if (napi_get_value_int32(env, v, out) != napi_ok) {
+        napi_throw_type_error(env, NULL, "expected an integer");
+        return 0;
+    }
+    return 1;
+}
+
+/* Float64Array -> (pointer, element count); null/undefined -> (NULL, 0) */
+static int get_f64_array(napi_env env, napi_value v, double **data, size_t *len)
+{
+    napi_valuetype t;
+    *data = NULL; *len = 0;
+    if (napi_typeof(env, v, &t) != napi_ok) return 0;
+    if (t == napi_null || t == napi_undefined) return 1;
+    bool is_ta = false;
+    napi_typedarray_type tt;
+    if (napi_is_typedarray(env, v, &is_ta) != napi_ok || !is_ta ||
+        napi_get_typedarray_info(env, v, &tt, len, (void **)data, NULL, NULL) != napi_ok || tt != napi_float64_array) {
+        napi_throw_type_error(env, NULL, "expected a Float64Array");
+        return 0;
+    }
+    return 1;
+}
+
+static napi_value js_create(napi_env env, napi_callback_info info)
+{
+    napi_value argv[1];
+    int32_t device = 0;
+    if (!get_args(env, info, 1, argv) || !get_i32(env, argv[0], &device)) return NULL;
+    ptr_ctx *ctx = NULL;
+    int rc = ptr_create(device, &ctx);
+    if (rc != PTR_OK) return throw_ptr(env, NULL, rc);
+    handle_cell *cell = (handle_cell *)malloc(sizeof *cell);
+    if (!cell) { ptr_destroy(ctx); napi_throw_error(env, NULL, "out of memory"); return NULL; }
+    cell->ctx = ctx;
+    napi_value h;
+    if (napi_create_external(env, cell, finalize_cell, NULL, &h) != napi_ok) {
+        ptr_destroy(ctx); free(cell);
+        napi_throw_error(env, NULL, "napi_create_external failed");
+        return NULL;
+    }
+    return h;
+}
+
+static napi_value js_destroy(napi_env env, napi_callback_info info)
+{
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    handle_cell *cell = NULL;
+    if (napi_get_value_external(env, argv[0], (void **)&cell) == napi_ok && cell && cell->ctx) {
+        ptr_destroy(cell->ctx);
+        cell->ctx = NULL;
+    }
+    return NULL;
+}
+
+static napi_value js_set_scene(napi_env env, napi_callback_info info)
+{
+    napi_value argv[4];
+    if (!get_args(env, info, 4, argv)) return NULL;
+    ptr_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    double *soa; size_t len;
+    int32_t n, frames;
+    if (!get_f64_array(env, argv[1], &soa, &len) || !get_i32(env, argv[2], &n) || !get_i32(env, argv[3], &frames))
+        return NULL;
+    if (n < 0 || frames < 1 || len < (size_t)12 * (size_t)n * (size_t)frames) {
+        napi_throw_range_error(env, "PTR_ERR_INVALID", "soa must hold 12 * n * nFrames numbers");
+        return NULL;
+    }
+    int rc = ptr_set_scene_sequence_f64(ctx, soa, n, frames);
+    if (rc != PTR_OK) return throw_ptr(env, ctx, rc);
+    return NULL;
+}
+
+static napi_value js_set_background(napi_env env, napi_callback_info info)
+{
+    napi_value argv[4];
+    if (!get_args(env, info, 4, argv)) return NULL;
+    ptr_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    double rgb[3];
+    for (int k = 0; k < 3; k++)
+        if (napi_get_value_double(env, argv[1 + k], &rgb[k]) != napi_ok) {
+            napi_throw_type_error(env, NULL, "background channels must be numbers");
+            return NULL;
+        }
+    int rc = ptr_set_background_f64(ctx, rgb);
+    if (rc != PTR_OK) return throw_ptr(env, ctx, rc);
+    return NULL;
+}
+
+static napi_value js_set_camera(napi_env env, napi_callback_info info)
+{
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return NULL;
+    ptr_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    double *v; size_t len;
+    if (!get_f64_array(env, argv[1], &v, &len)) return NULL;
+    int rc;
+    if (!v) rc = ptr_set_camera(ctx, NULL);
+    else {
+        if (len < 13) { napi_throw_range_error(env, "PTR_ERR_INVALID", "camera needs 13 numbers"); return NULL; }
+        ptr_camera cam;
+        memcpy(cam.origin, v, 3 * sizeof(double));
+        memcpy(cam.right, v + 3, 3 * sizeof(double));
+        memcpy(cam.up, v + 6, 3 * sizeof(double));
+        memcpy(cam.forward, v + 9, 3 * sizeof(double));
+        cam.tan_half_fov = v[12];
+        rc = ptr_set_camera(ctx, &cam);
+    }
+    if (rc != PTR_OK) return throw_ptr(env, ctx, rc);
+    return NULL;
+}
+
+static int read_params(napi_env env, napi_value *argv, ptr_params *p)
+{
+    int32_t flags;
+    memset(p, 0, sizeof *p);
+    if (!get_i32(env, argv[0], &p->width) || !get_i32(env, argv[1], &p->height) ||
+        !get_i32(env, argv[2], &p->start_y) || !get_i32(env, argv[3], &p->scan_height) ||
+        !get_i32(env, argv[4], &flags))
+        return 0;
+    p->flags = (uint32_t)flags;
+    p->spp = 1;
+    return 1;
+}
+
+static int check_frame_size(napi_env env, const ptr_params *p)
+{
+    /* RT/src/RayTracer.js:148 allocates width*scanHeight*4 bytes; keep it inside an ArrayBuffer */
+    if (p->width < 1 || p->height < 1 || p->scan_height < 1 ||
+        (uint64_t)p->width * (uint64_t)p->scan_height * 4u > 0x7fffffffull) {
+        napi_throw_range_error(env, "PTR_ERR_INVALID", "width/height/scanHeight must be >= 1 and width*scanHeight*4 < 2^31");
+        return 0;
+    }
+    return 1;
+}
+
+static napi_value js_render(napi_env env, napi_callback_info info)
+{
+    napi_value argv[6];
+    if (!get_args(env, info, 6, argv)) return NULL;
+    ptr_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    ptr_params p;
+    if (!read_params(env, argv + 1, &p) || !check_frame_size(env, &p)) return NULL;
+    void *data = NULL;
+    napi_value buf;
+    NAPI_TRY(env, napi_create_arraybuffer(env, (size_t)p.width * (size_t)p.scan_height * 4, &data, &buf));
+    int rc = ptr_render(ctx, &p, (uint32_t *)data, NULL);
+    if (rc != PTR_OK) return throw_ptr(env, ctx, rc);
+    return buf;            /* a fresh ArrayBuffer owned by the caller, RT/src/RayTracer.js:148,196 */
+}
+
+/* ---- renderAsync: the worker-shaped path (RT/src/RenderWorker.js:55-70) ------------------- */
+typedef struct {
+    ptr_ctx *ctx;
+    ptr_params p;
+    uint32_t *pixels;
+    int rc;
+    char err[512];
+    napi_deferred deferred;
+    napi_async_work work;
+    napi_ref handle_ref;        /* keeps the renderer alive while the job runs */
+} render_job;
+
+static void render_execute(napi_env env, void *data)
+{
+    (void)env;
+    render_job *j = (render_job *)data;
+    j->rc = ptr_render(j->ctx, &j->p, j->pixels, NULL);
+    if (j->rc != PTR_OK) {
+        strncpy(j->err, ptr_last_error(j->ctx), sizeof j->err - 1);
+        j->err[sizeof j->err - 1] = 0;
+    }
+}
+
+static void render_complete(napi_env env, napi_status status, void *data)
+{
+    render_job *j = (render_job *)data;
+    napi_value result;
+    if (status == napi_ok && j->rc == PTR_OK) {
+        void *dst = NULL;
+        size_t bytes = (size_t)j->p.width * (size_t)j->p.scan_height * 4;
+        if (napi_create_arraybuffer(env, bytes, &dst, &result) == napi_ok) {
+            memcpy(dst, j->pixels, bytes);
+            napi_resolve_deferred(env, j->deferred, result);
+        } else {
+            napi_value msg, err;
+            napi_create_string_utf8(env, "out of memory", NAPI_AUTO_LENGTH, &msg);
+            napi_create_error(env, NULL, msg, &err);
+            napi_reject_deferred(env, j->deferred, err);
+        }
+    } else {
+        napi_value msg, err;
+        napi_create_string_utf8(env, j->rc != PTR_OK ? j->err : "async work cancelled", NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, NULL, msg, &err);
+        napi_reject_deferred(env, j->deferred, err);
+    }
+    napi_delete_reference(env, j->handle_ref);
+    napi_delete_async_work(env, j->work);
+    free(j->pixels);
+    free(j);
+}
+
+static napi_value js_render_async(napi_env env, napi_callback_info info)
+{
+    napi_value argv[6];
+    if (!get_args(env, info, 6, argv)) return NULL;
+    ptr_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    render_job *j = (render_job *)calloc(1, sizeof *j);
+    if (!j) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
+    j->ctx = ctx;
+    if (!read_params(env, argv + 1, &j->p) || !check_frame_size(env, &j->p)) { free(j); return NULL; }
+    j->pixels = (uint32_t *)malloc((size_t)j->p.width * (size_t)j->p.scan_height * 4);
+    if (!j->pixels) { free(j); napi_throw_error(env, NULL, "out of memory"); return NULL; }
+    napi_value promise, name;
+    if (napi_create_promise(env, &j->deferred, &promise) != napi_ok ||
+        napi_create_reference(env, argv[0], 1, &j->handle_ref) != napi_ok ||
+        napi_create_string_utf8(env, "ptr_render", NAPI_AUTO_LENGTH, &name) != napi_ok ||
+        napi_create_async_work(env, NULL, name, render_execute, render_complete, j, &j->work) != napi_ok ||
+        napi_queue_async_work(env, j->work) != napi_ok) {
+        free(j->pixels); free(j);
+        napi_throw_error(env, NULL, "could not start the async render");
+        return NULL;
+    }
+    return promise;
+}
+
+static napi_value js_trace_batch(napi_env env, napi_callback_info info)
+{
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return NULL;
+    ptr_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    double *org, *dir; size_t no, nd;
+    if (!get_f64_array(env, argv[1], &org, &no) || !get_f64_array(env, argv[2], &dir, &nd)) return NULL;
+    if (!dir || nd % 3 != 0 || (org && no != nd)) {
+        napi_throw_range_error(env, "PTR_ERR_INVALID", "dirs must hold 3*n numbers and origins, if given, as many");
+        return NULL;
+    }
+    size_t n = nd / 3;
+    if (n > 0x3fffffff) { napi_throw_range_error(env, "PTR_ERR_INVALID", "too many rays"); return NULL; }
+    napi_value ab_rgb, ab_el, ab_hit, ab_nrm, rgb, el, hit, nrm, out;
+    void *d_rgb, *d_el, *d_hit, *d_nrm;
+    NAPI_TRY(env, napi_create_arraybuffer(env, n * 3 * sizeof(double), &d_rgb, &ab_rgb));
+    NAPI_TRY(env, napi_create_arraybuffer(env, n * sizeof(int32_t), &d_el, &ab_el));
+    NAPI_TRY(env, napi_create_arraybuffer(env, n * 3 * sizeof(double), &d_hit, &ab_hit));
+    NAPI_TRY(env, napi_create_arraybuffer(env, n * 3 * sizeof(double), &d_nrm, &ab_nrm));
+    int rc = ptr_trace_batch_f64(ctx, org, dir, (int)n, (double *)d_rgb, (int32_t *)d_el, (double *)d_hit, (double *)d_nrm);
+    if (rc != PTR_OK) return throw_ptr(env, ctx, rc);
+    NAPI_TRY(env, napi_create_typedarray(env, napi_float64_array, n * 3, ab_rgb, 0, &rgb));
+    NAPI_TRY(env, napi_create_typedarray(env, napi_int32_array, n, ab_el, 0, &el));
+    NAPI_TRY(env, napi_create_typedarray(env, napi_float64_array, n * 3, ab_hit, 0, &hit));
+    NAPI_TRY(env, napi_create_typedarray(env, napi_float64_array, n * 3, ab_nrm, 0, &nrm));
+    NAPI_TRY(env, napi_create_object(env, &out));
+    NAPI_TRY(env, napi_set_named_property(env, out, "rgb", rgb));
+    NAPI_TRY(env, napi_set_named_property(env, out, "element", el));
+    NAPI_TRY(env, napi_set_named_property(env, out, "hit", hit));
+    NAPI_TRY(env, napi_set_named_property(env, out, "normal", nrm));
+    return out;
+}
+
+static napi_value js_stats(napi_env env, napi_callback_info info)
+{
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    ptr_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    ptr_stats st;
+    int rc = ptr_get_stats(ctx, &st);
+    if (rc != PTR_OK) return throw_ptr(env, ctx, rc);
+    napi_value out, v;
+    NAPI_TRY(env, napi_create_object(env, &out));
+    const char *names[] = {"primary", "hits", "shadowRays", "exitTca", "exitD2", "exitHit", "retraced"};
+    const uint64_t vals[] = {st.primary, st.hits, st.shadow_rays, st.exit_tca, st.exit_d2, st.exit_hit, st.retraced};
+    for (int k = 0; k < 7; k++) {
+        NAPI_TRY(env, napi_create_double(env, (double)vals[k], &v));
+        NAPI_TRY(env, napi_set_named_property(env, out, names[k], v));
+    }
+    return out;
+}
+
+NAPI_MODULE_INIT()
+{
+    const struct { const char *name; napi_callback fn; } fns[] = {
+        {"create", js_create}, {"destroy", js_destroy}, {"setScene", js_set_scene},
+        {"setBackground", js_set_background}, {"setCamera", js_set_camera}, {"render", js_render},
+        {"renderAsync", js_render_async}, {"traceBatch", js_trace_batch}, {"stats", js_stats},
+    };
+    for (size_t k = 0; k < sizeof fns / sizeof fns[0]; k++) {
+        napi_value f;
+        if (napi_create_function(env, fns[k].name, NAPI_AUTO_LENGTH, fns[k].fn, NULL, &f) != napi_ok ||
+            napi_set_named_property(env, exports, fns[k].name, f) != napi_ok) {
+            napi_throw_error(env, NULL, "could not export the addon functions");
+            return NULL;
+        }
+    }
+    napi_value v;
+    const struct { const char *name; uint32_t val; } consts[] = {
+        {"QUIRK_ROW_SHIFT", PTR_QUIRK_ROW_SHIFT}, {"MODE_EXACT_F64", PTR_MODE_EXACT_F64},
+        {"MODE_F32_ONLY", PTR_MODE_F32_ONLY}, {"FLAG_STATS", PTR_FLAG_STATS}, {"ABI_VERSION", PTR_ABI_VERSION},
+    };
+    for (size_t k = 0; k < sizeof consts / sizeof consts[0]; k++) {
+        napi_create_uint32(env, consts[k].val, &v);
+        napi_set_named_property(env, exports, consts[k].name, v);
+    }
+    return exports;
+}

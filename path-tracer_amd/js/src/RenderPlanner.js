@@ -1,0 +1,90 @@
+import RayTracer from './RayTracer.js';
+import Scene from './Scene.js';
+import Sphere from './Sphere.js';
+import Vector3 from './Vector3.js';
+
+/**
+ * RenderPlanner — drop-in for raytracer-js-master/src/RenderPlanner.js:4-129.  The reference
+ * spawns `jobCount` WebWorkers, sends each the serialized scene and one scanline band, and calls
+ * onUpdateReceived(sectionStart, sectionHeight, buf8) as the bands come back.  Here a job is a band
+ * rendered on the GPU (jobs are dealt round-robin over `options.devices`, default [0]); the
+ * serialize -> deserialize hop of the worker protocol (Sphere.js:53-83, RenderWorker.js:27-46) is
+ * kept so that updateScene() has the same snapshot semantics.
+ *
+ * Band maths as in the reference (:75-76): sectionHeight = floor(height / jobCount),
+ * sectionStart = index * sectionHeight; rows past jobCount * sectionHeight are never rendered, and
+ * each band carries the row quirk of RayTracer.render().
+ */
+export default class RenderPlanner {
+    constructor(jobCount, scene, backgroundColor, width, height, options = {}) {
+        this.jobCount = jobCount;
+        this.scene = scene;
+        this.backgroundColor = backgroundColor;
+        this.width = width;
+        this.height = height;
+        this.running = false;
+        this.completedJobs = 0;
+        this.onUpdateReceived = function (sectionStart, sectionHeight, buf8) {};
+        this.onError = function (err) { throw err; };
+        this.serializeScene();
+
+        const devices = options.devices || [0];
+        this.workers = [];
+        for (let i = 0; i < jobCount; i++) {
+            // one renderer ("worker") per job, with its private copy of the scene
+            const w = { scene: new Scene(), background: new Vector3(0, 0, 0), dims: null };
+            w.tracer = new RayTracer(w.background, w.scene, undefined, { device: devices[i % devices.length], mode: options.mode });
+            this.workers.push(w);
+        }
+    }
+
+    initialize() {
+        for (let i = 0; i < this.workers.length; i++) this.prepareWorker(i, this.workers[i]);
+    }
+
+    start() {
+        this.running = true;
+        this.completedJobs = 0;
+        for (let i = 0; i < this.workers.length; i++) this.startWorker(this.workers[i]);
+    }
+
+    serializeScene() {
+        this.serializedElements = this.scene.getElements().map(el => el.serialize());
+    }
+
+    static _loadElements(worker, serialized) {
+        worker.scene.clear();
+        for (const e of serialized) worker.scene.add(Sphere.deserialize(e));
+    }
+
+    prepareWorker(index, worker) {
+        RenderPlanner._loadElements(worker, this.serializedElements);
+        worker.background.x = this.backgroundColor.x;
+        worker.background.y = this.backgroundColor.y;
+        worker.background.z = this.backgroundColor.z;
+        const sectionHeight = Math.floor(this.height / this.jobCount);
+        const sectionStart = Math.floor(index * sectionHeight);
+        worker.dims = [this.width, this.height, sectionStart, sectionHeight];
+    }
+
+    startWorker(worker) {
+        const [w, h, sectionStart, sectionHeight] = worker.dims;
+        worker.tracer.renderAsync(w, h, sectionStart, sectionHeight).then(buffer => {
+            this.completedJobs++;
+            if (this.completedJobs == this.jobCount) this.running = false;
+            this.onUpdateReceived(sectionStart, sectionHeight, new Uint8ClampedArray(buffer));
+        }).catch(err => {
+            this.running = false;          // the reference stalls forever here; surface the error instead
+            this.onError(err);
+        });
+    }
+
+    isRunning() { return this.running; }
+
+    updateScene() {
+        this.serializeScene();
+        for (const w of this.workers) RenderPlanner._loadElements(w, this.serializedElements);
+    }
+
+    dispose() { for (const w of this.workers) w.tracer.dispose(); }
+}

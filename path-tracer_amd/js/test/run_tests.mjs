@@ -1,0 +1,239 @@
+// Tests of the JavaScript host layer, written against the reference's API shape.
+//   node test/run_tests.mjs cpu   -> host logic only (no GPU): classes, wire format, error paths
+//   node test/run_tests.mjs gpu   -> renders through the N-API addon and compares with the golden
+//                                    vectors the unmodified reference produced (tests/golden/)
+import fs from 'fs';
+import path from 'path';
+import { fileURLToPath } from 'url';
+import assert from 'assert';
+import { Vector3, Material, Sphere, Scene, Color, Camera, RayTracer, RenderPlanner } from '../index.js';
+
+const here = path.dirname(fileURLToPath(import.meta.url));
+const golden = path.join(here, '..', '..', '..', 'tests', 'golden');
+const index = JSON.parse(fs.readFileSync(path.join(golden, 'index.json')));
+const scenes = JSON.parse(fs.readFileSync(path.join(golden, 'scenes.json')));
+const mode = process.argv[2] || 'cpu';
+let passed = 0;
+function test(name, fn) { fn(); passed++; console.log('ok   ' + name); }
+async function atest(name, fn) { await fn(); passed++; console.log('ok   ' + name); }
+
+function f64(file) { const b = fs.readFileSync(path.join(golden, file)); return new Float64Array(b.buffer, b.byteOffset, b.length / 8); }
+function u8(file) { return new Uint8Array(fs.readFileSync(path.join(golden, file))); }
+function sameBytes(a, b) { return Buffer.compare(Buffer.from(a.buffer || a, a.byteOffset || 0, a.byteLength), Buffer.from(b.buffer || b, b.byteOffset || 0, b.byteLength)) === 0; }
+
+// the scene-building lines of raytracer-js-master/examples/example1.js:9-45, unchanged
+function buildExample1() {
+    var scene = new Scene();
+    scene.add(new Sphere(new Vector3(0.0, -10004, -20), 10000, new Material(new Vector3(0.2, 0.2, 0.2), 0, 0, new Vector3())));
+    scene.add(new Sphere(new Vector3(0, 0, -20), 4, new Material(new Vector3(1.00, 0.32, 0.36), 1, 0.5, new Vector3())));
+    scene.add(new Sphere(new Vector3(5, -1, -15), 2, new Material(new Vector3(0.9, 0.76, 0.46), 1, 0, new Vector3())));
+    scene.add(new Sphere(new Vector3(5, 0, -25), 3, new Material(new Vector3(0.65, 0.77, 0.97), 1, 0, new Vector3())));
+    scene.add(new Sphere(new Vector3(-5.5, 0, -15), 3, new Material(new Vector3(0.9, 0.9, 0.9), 1, 0, new Vector3())));
+    scene.add(new Sphere(new Vector3(0, 20, -30), 3, new Material(new Vector3(), 0, 0, new Vector3(1.2, 1.2, 1.2))));
+    scene.add(new Sphere(new Vector3(0, 10, 10), 3, new Material(new Vector3(), 0, 0, new Vector3(1, 1, 1))));
+    return scene;
+}
+function sceneFrom(desc) { const s = new Scene(); for (const e of desc.elements) s.add(Sphere.deserialize(e)); return s; }
+
+function cpuTests() {
+    test('Vector3 in-place ops return this', () => {
+        const v = new Vector3(1, 2, 3);
+        assert.strictEqual(v.add(new Vector3(1, 1, 1)), v);
+        assert.deepStrictEqual([v.x, v.y, v.z], [2, 3, 4]);
+        assert.strictEqual(v.clone().multiply(2).subtract(v).dotProduct(new Vector3(1, 1, 1)), 9);
+        assert.strictEqual(new Vector3().normalize().length2(), 0);           // zero vector untouched
+        const n = new Vector3(3, 4, 0).normalize();
+        assert.strictEqual(n.x, 3 * (1 / Math.sqrt(25)));
+        const t = new Vector3(); new Vector3(7, 8, 9).copy(t); assert.deepStrictEqual([t.x, t.y, t.z], [7, 8, 9]);
+        assert.deepStrictEqual(Object.keys(new Vector3()), ['x', 'y', 'z']);
+        assert.strictEqual(new Vector3(1, -2, 3).revert().y, 2);
+        assert.strictEqual(new Vector3(1, 2, 3).product(new Vector3(2, 3, 4)).z, 12);
+    });
+    test('Material argument order and field names', () => {
+        const m = new Material(new Vector3(1, 2, 3), 0.25, 0.5, new Vector3(4, 5, 6));
+        assert.strictEqual(m.reflection, 0.25); assert.strictEqual(m.transparency, 0.5);
+        assert.strictEqual(m.surfaceColor.x, 1); assert.strictEqual(m.emissionColor.z, 6);
+    });
+    test('Sphere.intersect reproduces the reference table bit for bit', () => {
+        const rec = f64(index.intersect.file);
+        let hits = 0;
+        for (let k = 0; k < index.intersect.count; k++) {
+            const q = rec.subarray(k * 13, k * 13 + 13);
+            const sp = new Sphere(new Vector3(q[6], q[7], q[8]), q[9], new Material(new Vector3(), 0, 0, new Vector3()));
+            const out = { t0: 1e8, t1: 1e8 };
+            const hit = sp.intersect(new Vector3(q[0], q[1], q[2]), new Vector3(q[3], q[4], q[5]), out);
+            assert.strictEqual(hit ? 1 : 0, q[10]);
+            assert.ok(Object.is(out.t0, q[11]) && Object.is(out.t1, q[12]));
+            hits += hit;
+        }
+        assert.ok(hits > 50);
+    });
+    test('Sphere serialize / deserialize wire format', () => {
+        const s = buildExample1().getElements()[1];
+        const w = s.serialize();
+        assert.deepStrictEqual(w, scenes.example1.elements[1]);
+        const back = Sphere.deserialize(w);
+        assert.deepStrictEqual(back.serialize(), w);
+        assert.strictEqual(back.radius2, 16);
+        assert.strictEqual(back.getNormal(new Vector3(0, 4, -20)).y, 1);
+        assert.strictEqual(back.getCenter(), back.center); assert.strictEqual(back.getRadius(), 4);
+    });
+    test('Scene keeps order; flatten gives the C-ABI plane order', () => {
+        const sc = buildExample1();
+        assert.strictEqual(sc.getElements().length, 7);
+        const soa = RayTracer.flatten(sc.getElements());
+        assert.strictEqual(soa.length, 84);
+        assert.strictEqual(soa[1 * 7 + 0], -10004);   // cy of element 0
+        assert.strictEqual(soa[3 * 7 + 1], 4);        // radius of element 1
+        assert.strictEqual(soa[5 * 7 + 1], 0.32);     // sg of element 1
+        assert.strictEqual(soa[8 * 7 + 1], 0.5);      // transparency of element 1
+        assert.strictEqual(soa[9 * 7 + 5], 1.2);      // er of element 5
+        sc.clear(); assert.strictEqual(sc.getElements().length, 0);
+    });
+    test('Camera keeps its arguments (the reference mutates `to`)', () => {
+        const to = new Vector3(0, 0, -1);
+        const c = new Camera(new Vector3(0, 0, 0), to, 30, 640, 480);
+        assert.strictEqual(c.angle, Math.tan(Math.PI * 0.5 * 30 / 180));
+        assert.strictEqual(to.z, -1);
+        const b = c.basis();
+        assert.deepStrictEqual([b.right.x, b.up.y, b.forward.z], [1, 1, -1]);
+        assert.ok(new Color().r === 0);
+    });
+    test('no CPU fallback: constructing a RayTracer without a GPU throws', () => {
+        let threw = null;
+        try { new RayTracer(new Vector3(2, 2, 2), buildExample1()); } catch (e) { threw = e; }
+        if (process.env.PTR_EXPECT_GPU) return;
+        assert.ok(threw, 'expected an error without a GPU');
+        assert.ok(/no CPU fallback/.test(threw.message), threw.message);
+    });
+}
+
+async function gpuTests() {
+    test('example1.js scene lines + render(): bytes equal the reference frames', () => {
+        const bg = new Vector3(2.0, 2.0, 2.0);
+        const rt = new RayTracer(bg, buildExample1());
+        for (const key of ['example1@64x48', 'example1@160x120', 'example1@33x17']) {
+            const m = index.frames[key];
+            const buf = rt.render(m.width, m.height);
+            assert.ok(buf instanceof ArrayBuffer && buf.byteLength === m.width * m.height * 4);
+            assert.ok(sameBytes(new Uint8Array(buf), u8(m.file)), key);
+        }
+        assert.deepStrictEqual([bg.x, bg.y, bg.z], [2, 2, 2]);          // user's object untouched
+        assert.notStrictEqual(rt.render(8, 8), rt.render(8, 8));       // a fresh buffer each call
+        rt.dispose();
+    });
+    test('all three precision modes on every golden scene', () => {
+        for (const [key, m] of Object.entries(index.frames)) {
+            const desc = scenes[key.split('@')[0]];
+            for (const mode of ['hybrid', 'exact']) {
+                const rt = new RayTracer(new Vector3(...desc.background), sceneFrom(desc), undefined, { mode });
+                assert.ok(sameBytes(new Uint8Array(rt.render(m.width, m.height)), u8(m.file)), key + ' ' + mode);
+                rt.dispose();
+            }
+        }
+    });
+    test('scene objects are re-read on every render (example2.js mutates centres)', () => {
+        const scene = buildExample1();
+        const rt = new RayTracer(new Vector3(2, 2, 2), scene);
+        const a = Buffer.from(rt.render(64, 48));
+        const t = 1234, els = scene.getElements();
+        els[5].center = new Vector3(10 * Math.sin(t / 2000), 10, -30);
+        els[1].center = new Vector3(0, 5 * Math.sin(t / 1000), -20);
+        els[2].center = new Vector3(5, -1 * Math.sin(t / 500), -15);
+        els[3].center = new Vector3(5, 6 * Math.cos(t / 1000), -25);
+        els[4].center = new Vector3(-5.5, 3 * Math.cos(t / 1000), -15);
+        const b = rt.render(64, 48);
+        assert.ok(!sameBytes(a, new Uint8Array(b)));
+        assert.ok(sameBytes(new Uint8Array(b), u8(index.frames['anim_t1234@64x48'].file)));
+        rt.dispose();
+    });
+    test('trace() and requestPixel() against the reference per-ray vectors', () => {
+        const rt = new RayTracer(new Vector3(2, 2, 2), buildExample1());
+        const rec = f64(index.trace.example1.file);
+        const n = index.trace.example1.count;
+        const o = new Float64Array(3 * n), d = new Float64Array(3 * n);
+        for (let k = 0; k < n; k++) { o.set(rec.subarray(9 * k, 9 * k + 3), 3 * k); d.set(rec.subarray(9 * k + 3, 9 * k + 6), 3 * k); }
+        const r = rt.traceBatch(o, d);
+        for (let k = 0; k < n; k++) for (let c = 0; c < 3; c++) assert.ok(Object.is(r.rgb[3 * k + c], rec[9 * k + 6 + c]), `ray ${k}`);
+        const one = rt.trace(new Vector3(rec[0], rec[1], rec[2]), new Vector3(rec[3], rec[4], rec[5]), 0);
+        assert.ok(one instanceof Vector3 && Object.is(one.x, rec[6]));
+        const rp = f64(index.request_pixel.example1.file);
+        for (let k = 0; k < 40; k++) {
+            const c = rt.requestPixel(new Vector3(rp[6 * k], rp[6 * k + 1], rp[6 * k + 2]));
+            assert.deepStrictEqual([c.r, c.g, c.b], [rp[6 * k + 3], rp[6 * k + 4], rp[6 * k + 5]]);
+        }
+        const miss = rt.trace(new Vector3(0, 0, 0), new Vector3(0, 1, 0), 0);
+        assert.deepStrictEqual([miss.x, miss.y, miss.z], [2, 2, 2]);   // unclamped background
+        rt.dispose();
+    });
+    test('renderFrame(): every row at its true position', () => {
+        const rt = new RayTracer(new Vector3(2, 2, 2), buildExample1());
+        const w = 64, h = 48;
+        const shifted = new Uint32Array(rt.render(w, h)), plain = new Uint32Array(rt.renderFrame(w, h));
+        for (let y = 1; y < h; y++) for (let x = 0; x < w; x++) assert.strictEqual(plain[y * w + x], shifted[(y - 1) * w + x]);
+        assert.ok(plain.subarray((h - 1) * w).some(v => v !== 0));
+        rt.dispose();
+    });
+    test('argument validation', () => {
+        const rt = new RayTracer(new Vector3(2, 2, 2), buildExample1());
+        assert.throws(() => rt.render(0, 10), RangeError);
+        assert.throws(() => rt.render(NaN, 10), TypeError);
+        assert.throws(() => rt.render(65536, 65536), RangeError);
+        assert.throws(() => new RayTracer(new Vector3(), new Scene(), undefined, { mode: 'nope' }), TypeError);
+        const empty = new RayTracer(new Vector3(0.2, 0.4, 0.6), new Scene());
+        assert.ok(sameBytes(new Uint8Array(empty.render(64, 48)), u8(index.frames['empty@64x48'].file)));
+        rt.dispose(); empty.dispose();
+        assert.throws(() => rt.render(8, 8), /disposed/);
+    });
+    await atest('RenderPlanner: 8 bands, worker protocol semantics, bytes equal the reference bands', async () => {
+        const m = index.bands['example1@320x240/8'];
+        const scene = buildExample1();
+        const planner = new RenderPlanner(m.jobs, scene, new Vector3(2, 2, 2), m.width, m.height);
+        const pieces = [];
+        const done = new Promise((resolve, reject) => {
+            planner.onError = reject;
+            planner.onUpdateReceived = (start, height, buf8) => {
+                assert.ok(buf8 instanceof Uint8ClampedArray);
+                pieces.push({ start, height, buf8 });
+                if (planner.isRunning() == false) resolve();
+            };
+        });
+        planner.initialize();
+        assert.strictEqual(planner.isRunning(), false);
+        planner.start();
+        assert.strictEqual(planner.isRunning(), true);
+        await done;
+        assert.strictEqual(pieces.length, m.jobs);
+        pieces.sort((a, b) => a.start - b.start);
+        const all = Buffer.concat(pieces.map(p => Buffer.from(p.buf8)));
+        assert.ok(sameBytes(all, u8(m.file)));
+        assert.deepStrictEqual(pieces.map(p => p.start), [0, 30, 60, 90, 120, 150, 180, 210]);
+        // updateScene(): workers get a new snapshot; mutations after it are not seen until the next one
+        scene.getElements()[1].center = new Vector3(0, 3, -20);
+        planner.updateScene();
+        scene.getElements()[1].center = new Vector3(0, -3, -20);
+        const second = [];
+        const done2 = new Promise((resolve, reject) => {
+            planner.onError = reject;
+            planner.onUpdateReceived = (start, height, buf8) => { second.push({ start, buf8 }); if (!planner.isRunning()) resolve(); };
+        });
+        planner.start();
+        await done2;
+        const ref = new RayTracer(new Vector3(2, 2, 2), (() => { const s = buildExample1(); s.getElements()[1].center = new Vector3(0, 3, -20); return s; })());
+        second.sort((a, b) => a.start - b.start);
+        assert.ok(sameBytes(Buffer.from(second[3].buf8), new Uint8Array(ref.render(320, 240, 90, 30))));
+        ref.dispose(); planner.dispose();
+    });
+    test('stats(): the reference ray mix at 640x480 (SURVEY 6)', () => {
+        const rt = new RayTracer(new Vector3(2, 2, 2), buildExample1());
+        rt.render(640, 480);
+        const st = rt.stats();
+        assert.ok(st.retraced > 0 && st.retraced < 0.05 * 640 * 480);
+        rt.dispose();
+    });
+}
+
+(async () => {
+    if (mode === 'gpu') { process.env.PTR_EXPECT_GPU = '1'; cpuTests(); await gpuTests(); } else cpuTests();
+    console.log(`${passed} JS tests passed (${mode})`);
+})().catch(e => { console.error(e); process.exit(1); });
