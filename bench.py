@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="after timing, compare rank 0's gathered frame 0 with a single-GPU render")
     args = ap.parse_args()
 
     import torch
@@ -94,11 +95,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # PTR_BENCH_BACKEND=gloo is a rehearsal switch for boxes with fewer GPUs than ranks: ranks share
+    # GPUs (local_rank modulo the device count) and the gather is staged through host memory.
+    backend = os.environ.get("PTR_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     soa = example1_soa()
     bg = np.array([2.0, 2.0, 2.0])
@@ -139,7 +148,16 @@ def main():
         rdr.render_strips_device(p, part, 0, frames_total, local.data_ptr(), stream=stream,
                                  frame_stride_px=max_rows * WIDTH)
         if world > 1:
-            dist.gather(local, gathered, dst=0)
+            if backend == "nccl":
+                dist.gather(local, gathered, dst=0)
+            else:                                  # rehearsal: stage through the host
+                torch.cuda.synchronize()
+                host = local.cpu()
+                hl = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+                dist.gather(host, hl, dst=0)
+                if rank == 0:
+                    for r in range(world):
+                        gathered[r].copy_(hl[r])
             if rank == 0:
                 for r in range(world):
                     full.index_copy_(1, row_index[r], gathered[r][:, : row_index[r].numel(), :])
@@ -172,6 +190,13 @@ def main():
     main_ms = float(np.mean([k[0] for k in kms]))
     retrace_ms = float(np.mean([k[1] for k in kms]))
 
+    if args.check and rank == 0:
+        whole = torch.empty((HEIGHT, WIDTH), dtype=torch.int32, device="cuda")
+        rdr.render_device(rdr.params(WIDTH, HEIGHT, flags=0), 0, 1, whole.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        got = full[0] if world > 1 else local[0]
+        assert torch.equal(got, whole), "gathered frame differs from the single-GPU frame"
+        print("check ok: gathered frame == single-GPU frame", file=sys.stderr)
     if rank == 0:
         share = local_rows / HEIGHT                      # fraction of every frame this rank renders
         total_rays = rays_per_frame * frames_total       # all ranks together, per step
