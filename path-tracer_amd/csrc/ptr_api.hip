@@ -112,7 +112,7 @@ void default_camera(ptr_camera& cam)
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct BlockLayout {
-    uint32_t off_g64, off_m64, off_p32, off_m32, off_lights;
+    uint32_t off_g64, off_m64, off_p32, off_m32, off_lights, off_pairs;
     size_t   bytes;
 };
 
@@ -126,6 +126,11 @@ BlockLayout block_layout(int n)
     L.off_p32 = (uint32_t)o;    o += sizeof(SphereP32) * ((size_t)n + 2);   // + 2 zero records: look-ahead loads
     L.off_m32 = (uint32_t)o;    o += align_up(sizeof(SphereM32) * (size_t)n, 16);
     L.off_lights = (uint32_t)o; o += align_up(sizeof(int32_t) * (size_t)(n > 0 ? n : 1), 16);
+    // room for every element being a light: [n][n + 2] pre-filter records would be quadratic, so the
+    // table is sized for at most PTR_MAX_PAIR_LIGHTS lights; further lights are never culled
+    L.off_pairs = (uint32_t)o;
+    // (+ 1 row of never-cull records, used by the lights past the cap)
+    o += sizeof(PairQ) * ((size_t)(n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS) + 1) * ((size_t)n + 2);
     L.bytes = align_up(o, 256);
     return L;
 }
@@ -187,6 +192,29 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
         m.er = (float)er; m.eg = (float)eg; m.eb = (float)eb;
         m.emax = (float)std::fmax(er, std::fmax(eg, eb)) * 1.0000002f;
         m32[i] = m;
+    }
+    // shadow pre-filter table (see PairQ)
+    PairQ* pairs = reinterpret_cast<PairQ*>(dst + L.off_pairs);
+    for (int k = 0; k < nl && k < PTR_MAX_PAIR_LIGHTS; k++) {
+        const int i = lights[k];
+        for (int j = 0; j < n; j++) {
+            PairQ q{0.0f, 0.0f, 0.0f, -1.0f};                        // thr < 0: never culled
+            const double ax = pl(0, j) - pl(0, i), ay = pl(1, j) - pl(1, i), az = pl(2, j) - pl(2, i);
+            const double D = std::sqrt(ax * ax + ay * ay + az * az);
+            const double reach = std::fabs(pl(3, j)) + 1.0e-4 + 1.0e-6 * (std::fabs(pl(3, j)) + D);   // r + bias + slop
+            if (D > 0 && reach < D && std::isfinite(D)) {
+                const double x = reach / D;
+                const double thr = std::sqrt(1.0 - x * x);
+                q.ax = (float)(ax / D); q.ay = (float)(ay / D); q.az = (float)(az / D);
+                q.thr = (float)(thr * (1.0 - 4 * EPS32) - 10 * EPS32);   // rounding of a, of the dot, of thr itself
+            }
+            pairs[(size_t)k * ((size_t)n + 2) + (size_t)j] = q;
+        }
+        for (int j = n; j < n + 2; j++) pairs[(size_t)k * ((size_t)n + 2) + (size_t)j] = PairQ{0, 0, 0, -1.0f};
+    }
+    {
+        const size_t row = (size_t)(n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS);
+        for (int j = 0; j < n + 2; j++) pairs[row * ((size_t)n + 2) + (size_t)j] = PairQ{0, 0, 0, -1.0f};
     }
     for (int k = 0; k < 3; k++) {
         h->bg64[k] = bg[k];
@@ -276,7 +304,7 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
     a.frame_stride = c->frame_stride;
     {
         const BlockLayout L = block_layout(c->n_spheres);
-        a.off_p32 = L.off_p32; a.off_m32 = L.off_m32; a.off_lights = L.off_lights;
+        a.off_p32 = L.off_p32; a.off_m32 = L.off_m32; a.off_lights = L.off_lights; a.off_pairs = L.off_pairs;
         a.n = c->n_spheres;
     }
     a.first_frame = first_frame;

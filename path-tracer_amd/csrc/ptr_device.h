@@ -16,6 +16,7 @@
 #define PTR_BLOCK  256
 #define PTR_FAST_PPL 2            // pixels per lane in the float32 kernel (wave tile 8 x 16)
 #define PTR_MAX_QUEUES 1024       // sub-queues of the hybrid mode's re-trace queue
+#define PTR_MAX_PAIR_LIGHTS 64     // lights with a shadow pre-filter table (more lights: no culling for them)
 #define PTR_COUNTER_STRIDE 16     // uint32 words between two sub-queue counters (64 B)
 
 namespace ptr {
@@ -64,6 +65,12 @@ static_assert(sizeof(SphereP32) == 64, "SphereP32 layout");
 // material, gathered per lane for the winning sphere; scmax/emax = largest channel
 struct alignas(16) SphereM32 { float sr, sg, sb, scmax, er, eg, eb, emax; };
 
+// Shadow pre-filter, one record per (light k, element j), laid out [k][n + 2]:
+// a = unit vector from the light's centre to element j's centre, thr = lower bound of |L.a| for
+// which the line through the light with direction L can come within r_j (+ shadow bias) of C_j.
+// A shadow ray towards light k can only hit element j if |L.a| + (error of L) >= thr.
+struct alignas(16) PairQ { float ax, ay, az, thr; };
+
 struct FrameView {
     const FrameHeader* h;
     const SphereG64* g64;
@@ -104,7 +111,7 @@ struct CameraF32 {
 struct RenderArgs {
     const unsigned char* scenes;     // frame blocks, frame_stride bytes apart
     uint64_t  frame_stride;
-    uint32_t  off_p32, off_m32, off_lights;   // byte offsets inside a frame block (same for every frame)
+    uint32_t  off_p32, off_m32, off_lights, off_pairs;   // byte offsets inside a frame block (same for every frame)
     int32_t   n;                     // elements per frame
     int32_t   first_frame, n_frames;
     int32_t   width, height, start_y, scan_height;

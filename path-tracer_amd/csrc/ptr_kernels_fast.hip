@@ -43,9 +43,9 @@ typedef const volatile f4 PTR_CONST* ConstF4;      // a SphereP32 record = 4 x f
 // the 12 leading floats of a SphereP32 record (see ptr_device.h for the field names)
 struct P32Q { f4 g0, g1, g2; };
 __device__ __forceinline__ P32Q load_p32(ConstF4 rec) { return P32Q{rec[0], rec[1], rec[2]}; }
-// the 8 leading floats (shadow test)
-struct P32H { f4 g0, g1; };
-__device__ __forceinline__ P32H load_p32h(ConstF4 rec) { return P32H{rec[0], rec[1]}; }
+// the 8 leading floats (shadow test) + the (light, element) pre-filter record
+struct P32H { f4 g0, g1, pa; };
+__device__ __forceinline__ P32H load_p32h(ConstF4 rec, ConstF4 pair) { return P32H{rec[0], rec[1], pair[0]}; }
 // Scalar loads return out of order, so the only wait is "all of them": make the wave wait for the
 // record it is about to use BEFORE it requests the next one.  arrive() is an empty asm that
 // consumes every word of the record: that forces the wait here, and it keeps words the compute
@@ -60,9 +60,9 @@ __device__ __forceinline__ void arrive(const P32Q& q)
 __device__ __forceinline__ void arrive_after(const P32Q& q, float dep)
 { asm volatile("" ::PTR_F4_IN(q.g0), PTR_F4_IN(q.g1), PTR_F4_IN(q.g2), "v"(dep)); }
 __device__ __forceinline__ void arrive(const P32H& q)
-{ asm volatile("" ::PTR_F4_IN(q.g0), PTR_F4_IN(q.g1)); }
+{ asm volatile("" ::PTR_F4_IN(q.g0), PTR_F4_IN(q.g1), PTR_F4_IN(q.pa)); }
 __device__ __forceinline__ void arrive_after(const P32H& q, unsigned long long dep)
-{ asm volatile("" ::PTR_F4_IN(q.g0), PTR_F4_IN(q.g1), "s"(dep)); }
+{ asm volatile("" ::PTR_F4_IN(q.g0), PTR_F4_IN(q.g1), PTR_F4_IN(q.pa), "s"(dep)); }
 
 __device__ __forceinline__ float dot3(F3 a, F3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
@@ -125,12 +125,14 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
     const ConstF4 rec0 = (ConstF4)(uintptr_t)(block + a.off_p32);          // uniform reads, 4 f4 per sphere
     const ConstM32 cm32 = (ConstM32)(uintptr_t)(block + a.off_m32);
     const ConstI32 clights = (ConstI32)(uintptr_t)(block + a.off_lights);
+    const ConstF4 pairs0 = (ConstF4)(uintptr_t)(block + a.off_pairs);      // [light][n + 2] pre-filter records
     const SphereP32* gp32 = reinterpret_cast<const SphereP32*>(block + a.off_p32);   // per-lane gathers
     const SphereM32* gm32 = reinterpret_cast<const SphereM32*>(block + a.off_m32);
     const int n = a.n;
 
     // ---- this lane's pixels: an 8 x (8*PPL) tile per wave, 32 x (8*PPL) per workgroup ------------
     Pixel px[PPL];
+    [[maybe_unused]] unsigned dbg_full_tests = 0, dbg_pre_tests = 0;   // DBG: shadow tests this wave ran
     Unsure<DBG> unsure[PPL];
 #pragma unroll
     for (int p = 0; p < PPL; p++) {
@@ -267,6 +269,20 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
         // ---- direct light + binary shadow (RayTracer.js:61-91) ---------------------------------
         // one shadow test of sphere record pj for every pixel slot
         auto shadow = [&](const P32H& pj) {
+            if constexpr (DBG) dbg_pre_tests++;
+            // Pre-filter: the shadow ray leaves (within the 1e-4 bias) along the line through the
+            // light's centre, so it can only reach element j if that line does: |L.a| >= thr, with
+            // the error of L added on the safe side.  Most (light, element) pairs fail this for every
+            // lane of the wave, and the whole test below is skipped.
+            unsigned long long near_m = 0ull;
+#pragma unroll
+            for (int p = 0; p < PPL; p++) {
+                const Shade& s = sh[p];
+                const float c = fmaf(pj.pa.z, s.L.z, fmaf(pj.pa.y, s.L.y, pj.pa.x * s.L.x));
+                near_m |= ballot(fabsf(c) + s.cL >= pj.pa.w) & s.open_m;   // thr carries 5 more eps of slack
+            }
+            if (near_m == 0ull) return;
+            if constexpr (DBG) dbg_full_tests++;
 #pragma unroll
             for (int p = 0; p < PPL; p++) {
                 Shade& s = sh[p];
@@ -295,19 +311,21 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
             return m == 0ull;
         };
         // occluders j0 .. j1-1 (the light itself is left out by the caller, RayTracer.js:76)
-        auto shadow_range = [&](int j0, int j1) {
+        auto shadow_range = [&](ConstF4 pairs, int j0, int j1) {
             if (j0 >= j1) return;
             ConstF4 rec = rec0 + 4 * j0;
-            P32H A = load_p32h(rec);
+            ConstF4 pr = pairs + j0;
+            P32H A = load_p32h(rec, pr);
             for (int j = j0; j < j1; j += 2) {
                 if (all_closed()) break;
                 arrive(A);
-                const P32H B = load_p32h(rec + 4);
+                const P32H B = load_p32h(rec + 4, pr + 1);
                 shadow(A);
                 arrive_after(B, sh[PPL - 1].open_m);
-                A = load_p32h(rec + 8);
+                A = load_p32h(rec + 8, pr + 2);
                 if (j + 1 < j1) shadow(B);
                 rec += 8;
+                pr += 2;
             }
             arrive(A);
         };
@@ -315,7 +333,10 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
         const int nl = hdr->n_lights;
         for (int k = 0; k < nl; k++) {
             const int i = clights[k];
-            const P32H pl = load_p32h(rec0 + 4 * i);
+            // lights past the table's capacity share a record that never culls (thr < 0)
+            const int prow = k < PTR_MAX_PAIR_LIGHTS ? k : (n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS);
+            const ConstF4 pairs = pairs0 + (size_t)prow * (size_t)(n + 2);
+            const P32H pl = load_p32h(rec0 + 4 * i, pairs);
             const float ler = cm32[i].er, leg = cm32[i].eg, leb = cm32[i].eb, lemax = cm32[i].emax;
 #pragma unroll
             for (int p = 0; p < PPL; p++) {
@@ -331,8 +352,8 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
                 s.open_m = ballot((s.ratio > 0.0f) & s.valid);
                 s.maybe_m = 0ull; s.blocked_m = 0ull;
             }
-            shadow_range(0, i);
-            shadow_range(i + 1, n);
+            shadow_range(pairs, 0, i);
+            shadow_range(pairs, i + 1, n);
 #pragma unroll
             for (int p = 0; p < PPL; p++) {
                 Shade& s = sh[p];
@@ -376,7 +397,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
     for (int p = 0; p < PPL; p++) {
         const Pixel& r = px[p];
         if (!r.live) continue;
-        if constexpr (DBG) packed[p] = unsure[p].why();
+        if constexpr (DBG) packed[p] = unsure[p].why() | (dbg_full_tests << 8) | (dbg_pre_tests << 16);
         long long idx_out = (long long)a.width * r.row + r.x;
         if (quirk) idx_out -= a.width;
         if (idx_out >= 0) out8[idx_out] = packed[p];
