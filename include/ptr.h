@@ -58,16 +58,38 @@ typedef struct ptr_ctx ptr_ctx;
 
 /* Replaces the argument list of RayTracer.render(width,height,startY,scanHeight,isFirstFrame)
  * (RT/src/RayTracer.js:132).  isFirstFrame is unused by the reference and has no field.
- * max_depth/spp/seed belong to the extension modes (reflection bounces / stochastic sampling,
- * which the reference does not implement — SURVEY.md F1,F3); they must be 0/1/any here.     */
+ * max_depth/spp/seed select the EXTENSION modes (reflection/refraction bounces, stochastic
+ * sampling), which the reference does not implement (MAX_RAY_DEPTH and
+ * Material.reflection/.transparency are never read): no reference parity exists for them.  Their
+ * specification (float64, one rounding per operation, evaluated in the order written):
+ *   stack <- (origin, dir, depth 0, weight (1,1,1));  acc <- 0
+ *   pop (o, d, depth, w):  nearest hit exactly as RayTracer.trace (RayTracer.js:26-41);
+ *     miss: acc += w * background
+ *     hit:  acc += w * emission;  N flipped to face the ray, inside = it was flipped
+ *       if (transparency > 0 || reflection > 0) && depth < max_depth:
+ *           f = 1 - (-(d.N));  fresnel = 1*0.1 + (f*f*f)*(1 - 0.1)
+ *           if transparency > 0: eta = inside ? 1.1 : 1/1.1;  cosi = -(N.d);
+ *               k = 1 - eta*eta*(1 - cosi*cosi);
+ *               if k >= 0: push (P - N*1e-4, normalize(d*eta + N*(eta*cosi - sqrt(k))), depth+1,
+ *                                w * surfaceColor * ((1 - fresnel) * transparency))
+ *           push (P + N*1e-4, normalize(d - N*(2*(d.N))), depth+1, w * surfaceColor * fresnel)
+ *       else: acc += w * (the shadowed Lambert sum of RayTracer.js:60-91)
+ *   spp > 1: sample s of pixel (x, y) goes through (x + u0, y + u1), (u0, u1) = the first two words
+ *   of Philox4x32-10(counter (x, y, s, 0), key (seed, 0x50545221)), u = (word + 0.5) / 2^32; the
+ *   pixel is the mean of the samples (summed in sample order, one divide), then packed as ever.
+ * With max_depth 0 and spp 1 a call has the reference semantics.  In the extension modes PTR_MODE_EXACT_F64 renders that specification bit
+ * for bit, any other mode renders it in float32 (tolerance: see tests/test_gpu_ext.py);
+ * PTR_QUIRK_ROW_SHIFT and PTR_FLAG_STATS are rejected.                                       */
+#define PTR_MAX_DEPTH_LIMIT 16
+#define PTR_MAX_SPP         65536
 typedef struct ptr_params {
     int32_t  width;        /* full image width  (RayTracer.js:150,153)                        */
     int32_t  height;       /* full image height (RayTracer.js:151,153)                        */
     int32_t  start_y;      /* first scanline of the band (RayTracer.js:134-136), default 0    */
     int32_t  scan_height;  /* rows in the band (RayTracer.js:138-140), default = height       */
-    int32_t  max_depth;    /* 0 = reference semantics (no bounce exists in the reference)     */
-    int32_t  spp;          /* 1                                                               */
-    uint32_t seed;         /* unused at spp = 1                                               */
+    int32_t  max_depth;    /* 0 = reference semantics (no bounce exists in the reference); <= 16 */
+    int32_t  spp;          /* 1 = pixel centre; > 1: Philox4x32-10 jittered samples, averaged   */
+    uint32_t seed;         /* Philox key word 0; unused at spp = 1                             */
     uint32_t flags;        /* PTR_QUIRK_* | PTR_MODE_* | PTR_FLAG_*                           */
 } ptr_params;
 

@@ -1,0 +1,59 @@
+"""TEST INFRASTRUCTURE — regression vectors for the EXTENSION modes (max_depth > 0, spp > 1).
+
+The reference has no such modes, so these files are NOT reference outputs: they
+are outputs of the float64 specification in oracle/ptr_oracle.c (orc_render_ext), frozen so that a
+later edit of the specification shows up as a diff ("self-pinned, parity unpinned").
+Run from the repo root:  python oracle/gen_golden_ext.py
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+import oracle_py as orc  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+CASES = [   # scene, width, height, max_depth, spp, seed, keep the frame (else hash only)
+    ("example1", 160, 120, 5, 1, 0, True),
+    ("example1", 160, 120, 1, 1, 0, True),
+    ("example1", 160, 120, 0, 4, 7, True),
+    ("example1", 160, 120, 5, 4, 7, True),
+    ("example1_permuted", 96, 64, 5, 2, 1, True),
+    ("random_3", 96, 64, 5, 1, 0, True),
+    ("random_5", 96, 64, 3, 2, 99, True),
+    ("inside_sphere", 64, 48, 5, 1, 0, True),
+    ("example1", 640, 480, 5, 1, 0, False),
+    ("example1", 640, 480, 5, 4, 12345, False),
+    ("example1", 1920, 1080, 5, 1, 0, False),
+]
+
+
+def main():
+    scenes = orc.load_scenes(GOLDEN)
+    index = {"note": "outputs of oracle/ptr_oracle.c orc_render_ext (the extension-mode specification); "
+                     "not reference outputs", "cases": {}}
+    os.makedirs(os.path.join(GOLDEN, "ext"), exist_ok=True)
+    for name, w, h, depth, spp, seed, keep in CASES:
+        sc = scenes[name]
+        soa = orc.scene_to_soa(sc["elements"])
+        out = orc.render_ext(soa, sc["background"], w, h, max_depth=depth, spp=spp, seed=seed, threads=8)
+        key = f"{name}@{w}x{h}_d{depth}_s{spp}_k{seed}"
+        entry = dict(scene=name, width=w, height=h, max_depth=depth, spp=spp, seed=seed,
+                     sha256=hashlib.sha256(out.tobytes()).hexdigest())
+        if keep:
+            rel = f"ext/{key}.rgba"
+            out.tofile(os.path.join(GOLDEN, rel))
+            entry["file"] = rel
+        index["cases"][key] = entry
+        print(key, entry["sha256"][:16])
+    with open(os.path.join(GOLDEN, "ext", "index.json"), "w") as f:
+        json.dump(index, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

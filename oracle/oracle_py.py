@@ -57,6 +57,13 @@ def lib():
         L.orc_render_mt.restype = None
         L.orc_render_rgb64.argtypes = [dp, C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, dp]
         L.orc_render_rgb64.restype = None
+        L.orc_trace_ext.argtypes = [dp, C.c_int, dp, dp, dp, C.c_int, dp]
+        L.orc_trace_ext.restype = None
+        L.orc_render_ext.argtypes = [dp, C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_uint32, C.POINTER(C.c_uint32), dp, C.c_int]
+        L.orc_render_ext.restype = None
+        L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.orc_philox4x32_10.restype = None
         L.orc_pack.argtypes = [dp]
         L.orc_pack.restype = C.c_uint32
         L.orc_reference_angle.restype = C.c_double
@@ -170,3 +177,33 @@ def intersect(o, d, c, radius):
 def pack(rgb):
     rgb = np.ascontiguousarray(rgb, dtype=np.float64)
     return int(lib().orc_pack(_dp(rgb)))
+
+
+# ---- extension modes (spec only; parity unpinned by the reference) ----------------------------
+def render_ext(soa, bg, width, height, start_y=0, scan_height=None, max_depth=0, spp=1, seed=0,
+               want_rgb64=False, threads=8):
+    if scan_height is None:
+        scan_height = height
+    soa = np.ascontiguousarray(soa, dtype=np.float64)
+    bg = np.ascontiguousarray(bg, dtype=np.float64)
+    out = np.empty(width * scan_height, dtype=np.uint32)
+    rgb = np.empty((scan_height, width, 3), dtype=np.float64) if want_rgb64 else None
+    lib().orc_render_ext(_dp(soa), soa.shape[1], _dp(bg), width, height, start_y, scan_height, max_depth, spp,
+                         seed, out.ctypes.data_as(C.POINTER(C.c_uint32)), _dp(rgb) if want_rgb64 else None, threads)
+    return (out, rgb) if want_rgb64 else out
+
+
+def trace_ext(soa, bg, o, d, max_depth):
+    soa = np.ascontiguousarray(soa, dtype=np.float64)
+    bg = np.ascontiguousarray(bg, dtype=np.float64)
+    o = np.ascontiguousarray(o, dtype=np.float64)
+    d = np.ascontiguousarray(d, dtype=np.float64)
+    rgb = np.empty(3, dtype=np.float64)
+    lib().orc_trace_ext(_dp(soa), soa.shape[1], _dp(bg), _dp(o), _dp(d), max_depth, _dp(rgb))
+    return rgb
+
+
+def philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr); k = (C.c_uint32 * 2)(*key); o = (C.c_uint32 * 4)()
+    lib().orc_philox4x32_10(c, k, o)
+    return list(o)

@@ -261,3 +261,183 @@ void orc_render_rgb64(const double *soa, int n, const double bg[3],
                       out_rgb + 3 * ((size_t)width * (size_t)(y - start_y) + (size_t)x), 0, 0);
         }
 }
+
+
+/* ======================= EXTENSION modes (spec; see ptr_oracle.h) ============================ */
+
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    /* Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11) */
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+#define ORC_MAX_DEPTH 16
+
+typedef struct { double o[3], d[3], w[3]; int depth; } ext_ray;
+
+/* nearest hit + hit frame shared by every node of the expansion (same arithmetic as orc_trace) */
+static int ext_nearest(const double *soa, int n, const double o[3], const double d[3], double *tnear_out)
+{
+    const double *cx = PL(0), *cy = PL(1), *cz = PL(2), *rad = PL(3);
+    double tnear = ORC_INFINITY;
+    int element = -1;
+    for (int i = 0; i < n; i++) {
+        double t0 = ORC_INFINITY, t1 = ORC_INFINITY;
+        if (intersect_r2(o, d, cx[i], cy[i], cz[i], rad[i] * rad[i], &t0, &t1, 0)) {
+            if (t0 < 0) t0 = t1;
+            if (t0 < tnear) { tnear = t0; element = i; }
+        }
+    }
+    *tnear_out = tnear;
+    return element;
+}
+
+void orc_trace_ext(const double *soa, int n, const double bg[3],
+                   const double o[3], const double d[3], int max_depth, double rgb[3])
+{
+    const double *cx = PL(0), *cy = PL(1), *cz = PL(2), *rad = PL(3);
+    const double *sr = PL(4), *sg = PL(5), *sb = PL(6), *refl = PL(7), *transp = PL(8);
+    const double *er = PL(9), *eg = PL(10), *eb = PL(11);
+    if (max_depth > ORC_MAX_DEPTH) max_depth = ORC_MAX_DEPTH;
+    ext_ray stack[ORC_MAX_DEPTH + 2];
+    int top = 0;
+    double acc[3] = { 0, 0, 0 };
+    memcpy(stack[0].o, o, sizeof stack[0].o); memcpy(stack[0].d, d, sizeof stack[0].d);
+    stack[0].w[0] = stack[0].w[1] = stack[0].w[2] = 1.0; stack[0].depth = 0;
+    top = 1;
+    while (top > 0) {
+        const ext_ray r = stack[--top];
+        double tnear;
+        const int e = ext_nearest(soa, n, r.o, r.d, &tnear);
+        if (e < 0) {
+            acc[0] += r.w[0] * bg[0]; acc[1] += r.w[1] * bg[1]; acc[2] += r.w[2] * bg[2];
+            continue;
+        }
+        acc[0] += r.w[0] * er[e]; acc[1] += r.w[1] * eg[e]; acc[2] += r.w[2] * eb[e];
+        double P[3] = { r.o[0] + r.d[0] * tnear, r.o[1] + r.d[1] * tnear, r.o[2] + r.d[2] * tnear };
+        double N[3] = { P[0] - cx[e], P[1] - cy[e], P[2] - cz[e] };
+        v_normalize(N);
+        int inside = 0;
+        double dn = r.d[0] * N[0] + r.d[1] * N[1] + r.d[2] * N[2];
+        if (dn > 0) { N[0] = -N[0]; N[1] = -N[1]; N[2] = -N[2]; inside = 1; dn = -dn; }
+        if ((transp[e] > 0 || refl[e] > 0) && r.depth < max_depth) {
+            const double facing = -dn;
+            const double f = 1 - facing;
+            const double fresnel = 1 * 0.1 + (f * f * f) * (1 - 0.1);
+            const double wsc[3] = { r.w[0] * sr[e], r.w[1] * sg[e], r.w[2] * sb[e] };
+            if (transp[e] > 0) {
+                const double eta = inside ? 1.1 : 1 / 1.1;
+                const double cosi = -dn;
+                const double k = 1 - eta * eta * (1 - cosi * cosi);
+                if (k >= 0) {
+                    ext_ray *c = &stack[top++];
+                    const double g = eta * cosi - sqrt(k);
+                    const double wt = (1 - fresnel) * transp[e];
+                    for (int a = 0; a < 3; a++) {
+                        c->o[a] = P[a] - N[a] * ORC_BIAS;
+                        c->d[a] = r.d[a] * eta + N[a] * g;
+                        c->w[a] = wsc[a] * wt;
+                    }
+                    v_normalize(c->d);
+                    c->depth = r.depth + 1;
+                }
+            }
+            ext_ray *c = &stack[top++];
+            const double two = 2 * dn;
+            for (int a = 0; a < 3; a++) {
+                c->o[a] = P[a] + N[a] * ORC_BIAS;
+                c->d[a] = r.d[a] - N[a] * two;
+                c->w[a] = wsc[a] * fresnel;
+            }
+            v_normalize(c->d);
+            c->depth = r.depth + 1;
+        } else {
+            /* the reference's direct lighting (RayTracer.js:60-91) */
+            double dif[3] = { 0, 0, 0 };
+            for (int i = 0; i < n; i++) {
+                if (er[i] > 0 || eg[i] > 0 || eb[i] > 0) {
+                    double tr = 1.0;
+                    double L[3] = { cx[i] - P[0], cy[i] - P[1], cz[i] - P[2] };
+                    v_normalize(L);
+                    for (int j = 0; j < n; j++) {
+                        if (i != j) {
+                            double so[3] = { P[0] + N[0] * ORC_BIAS, P[1] + N[1] * ORC_BIAS, P[2] + N[2] * ORC_BIAS };
+                            double t0, t1;
+                            if (intersect_r2(so, L, cx[j], cy[j], cz[j], rad[j] * rad[j], &t0, &t1, 0)) { tr = 0.0; break; }
+                        }
+                    }
+                    double ratio = js_max0(N[0] * L[0] + N[1] * L[1] + N[2] * L[2]);
+                    dif[0] += (sr[e] * tr) * (er[i] * ratio);
+                    dif[1] += (sg[e] * tr) * (eg[i] * ratio);
+                    dif[2] += (sb[e] * tr) * (eb[i] * ratio);
+                }
+            }
+            acc[0] += r.w[0] * dif[0]; acc[1] += r.w[1] * dif[1]; acc[2] += r.w[2] * dif[2];
+        }
+    }
+    rgb[0] = acc[0]; rgb[1] = acc[1]; rgb[2] = acc[2];
+}
+
+typedef struct {
+    const double *soa; int n; const double *bg; int width, height, start_y, scan_height;
+    int max_depth, spp; uint32_t seed; uint32_t *out8; double *out64; int first, step;
+} ext_job;
+
+static void *ext_main(void *p)
+{
+    const ext_job *j = (const ext_job *)p;
+    const double invW = 1.0 / j->width, invH = 1.0 / j->height;
+    const double aspect = (double)j->width / (double)j->height, angle = orc_reference_angle();
+    const double origin[3] = { 0, 0, 0 };
+    for (int y = j->start_y + j->first; y < j->start_y + j->scan_height; y += j->step)
+        for (int x = 0; x < j->width; x++) {
+            double sum[3] = { 0, 0, 0 };
+            for (int s = 0; s < j->spp; s++) {
+                double px = x + 0.5, py = y + 0.5;
+                if (j->spp > 1) {
+                    const uint32_t ctr[4] = { (uint32_t)x, (uint32_t)y, (uint32_t)s, 0u };
+                    const uint32_t key[2] = { j->seed, 0x50545221u };
+                    uint32_t rnd[4];
+                    orc_philox4x32_10(ctr, key, rnd);
+                    px = x + (rnd[0] + 0.5) / 4294967296.0;
+                    py = y + (rnd[1] + 0.5) / 4294967296.0;
+                }
+                double dir[3] = { (2 * (px * invW) - 1) * angle * aspect, (1 - 2 * (py * invH)) * angle, -1 };
+                v_normalize(dir);
+                double c[3];
+                orc_trace_ext(j->soa, j->n, j->bg, origin, dir, j->max_depth, c);
+                sum[0] += c[0]; sum[1] += c[1]; sum[2] += c[2];
+            }
+            if (j->spp > 1) { sum[0] /= j->spp; sum[1] /= j->spp; sum[2] /= j->spp; }
+            const size_t idx = (size_t)j->width * (size_t)(y - j->start_y) + (size_t)x;
+            if (j->out8) j->out8[idx] = orc_pack(sum);
+            if (j->out64) { j->out64[3 * idx] = sum[0]; j->out64[3 * idx + 1] = sum[1]; j->out64[3 * idx + 2] = sum[2]; }
+        }
+    return 0;
+}
+
+void orc_render_ext(const double *soa, int n, const double bg[3],
+                    int width, int height, int start_y, int scan_height,
+                    int max_depth, int spp, uint32_t seed,
+                    uint32_t *out_rgba8, double *out_rgb64, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (spp < 1) spp = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    ext_job *jobs = (ext_job *)malloc(sizeof(ext_job) * (size_t)nthreads);
+    for (int t = 0; t < nthreads; t++) {
+        ext_job j = { soa, n, bg, width, height, start_y, scan_height, max_depth, spp, seed, out_rgba8, out_rgb64, t, nthreads };
+        jobs[t] = j;
+        pthread_create(&th[t], 0, ext_main, &jobs[t]);
+    }
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], 0);
+    free(th); free(jobs);
+}

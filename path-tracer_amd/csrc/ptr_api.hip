@@ -164,7 +164,7 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
         if (sr < 0 || sg < 0 || sb < 0 || er < 0 || eg < 0 || eb < 0) needs_exact = true;
 
         g64[i] = SphereG64{cx, cy, cz, r * r};          // radius2 = radius*radius, Sphere.js:11
-        m64[i] = SphereM64{sr, sg, sb, er, eg, eb};
+        m64[i] = SphereM64{sr, sg, sb, er, eg, eb, pl(7, i), pl(8, i)};
         if (er > 0 || eg > 0 || eb > 0) lights[nl++] = i;   // RayTracer.js:65-66
 
         const double lx = cx - org[0], ly = cy - org[1], lz = cz - org[2];
@@ -185,6 +185,7 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
         p.lnorm = (float)(lnorm * (1.0 + 2 * EPS32) + 2.1e-4);   // upper bound of |l| + shadow bias
         p.inv_r = (float)(1.0 / std::fmax(rad, 1e-30));
         p.hed = (float)(10.0 * EPS32 * rad * lnorm + 2.0 * EPS32 * r2);
+        p.refl = (float)pl(7, i); p.transp = (float)pl(8, i);
         p32[i] = p;
         SphereM32 m;
         m.sr = (float)sr; m.sg = (float)sg; m.sb = (float)sb;
@@ -270,10 +271,18 @@ int check_params(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frames)
                     (unsigned long long)px);
     if ((p->scan_height + PTR_TILE_H - 1) / PTR_TILE_H > 65535)
         return fail(c, PTR_ERR_INVALID, "scan_height too large (%d)", p->scan_height);
-    if (p->max_depth != 0 || p->spp != 1)
-        return fail(c, PTR_ERR_UNSUPPORTED,
-                    "max_depth=%d spp=%d: only the reference semantics (max_depth 0, spp 1) are built",
-                    p->max_depth, p->spp);
+    if (p->max_depth < 0 || p->max_depth > PTR_MAX_DEPTH_LIMIT || p->spp < 1 || p->spp > PTR_MAX_SPP)
+        return fail(c, PTR_ERR_INVALID, "max_depth must be in [0, %d] and spp in [1, %d] (got %d, %d)",
+                    PTR_MAX_DEPTH_LIMIT, PTR_MAX_SPP, p->max_depth, p->spp);
+    if (p->max_depth != 0 || p->spp != 1) {
+        // extension modes (ptr_kernels_ext.hip): not reference behaviour, so no reference quirk and no
+        // reference work counters exist for them
+        if (p->flags & PTR_QUIRK_ROW_SHIFT)
+            return fail(c, PTR_ERR_INVALID, "PTR_QUIRK_ROW_SHIFT applies to the reference semantics only "
+                                            "(max_depth 0, spp 1); got max_depth=%d spp=%d", p->max_depth, p->spp);
+        if (p->flags & PTR_FLAG_STATS)
+            return fail(c, PTR_ERR_UNSUPPORTED, "PTR_FLAG_STATS counts the reference path only (max_depth 0, spp 1)");
+    }
     if ((p->flags & PTR_MODE_EXACT_F64) && (p->flags & PTR_MODE_F32_ONLY))
         return fail(c, PTR_ERR_INVALID, "PTR_MODE_EXACT_F64 and PTR_MODE_F32_ONLY are exclusive");
     return PTR_OK;
@@ -346,6 +355,13 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
         HIP_TRY(c, hipEventRecord(c->ev[0], s));
     }
 
+    if (p->max_depth != 0 || p->spp != 1) {
+        // extension modes: float64 = the specification bit for bit; anything else = float32 throughput form
+        a.max_depth = p->max_depth; a.spp = p->spp; a.seed = p->seed;
+        HIP_TRY(c, launch_render_ext(a, n_frames, exact, s));
+        if (timing) { HIP_TRY(c, hipEventRecord(c->ev[1], s)); c->timed_kernels = 1; }
+        return PTR_OK;
+    }
     if (exact) {
         HIP_TRY(c, launch_render_exact(a, n_frames, stats, s));
         if (timing) { HIP_TRY(c, hipEventRecord(c->ev[1], s)); c->timed_kernels = 1; }
@@ -360,10 +376,9 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
     const int rpb = fast_kernel_rows_per_block();
     const uint64_t n_blocks = (uint64_t)((p->width + PTR_TILE_W - 1) / PTR_TILE_W) *
                               (uint64_t)((p->scan_height + rpb - 1) / rpb) * (uint64_t)n_frames;
-    uint64_t n_queues = n_blocks / 4;
-    if (n_queues < 1) n_queues = 1;
-    if (n_queues > PTR_MAX_QUEUES) n_queues = PTR_MAX_QUEUES;
-    // a workgroup can queue at most PTR_BLOCK pixels; sub-queue s serves the workgroups b with b % n_queues == s
+    uint64_t n_queues = 1;                                     // a power of two (the kernel masks)
+    while (n_queues * 2 <= PTR_MAX_QUEUES && n_queues * 8 <= n_blocks) n_queues *= 2;
+    // a workgroup can queue at most PTR_BLOCK pixels; sub-queue s serves the workgroups b with (b & (n_queues - 1)) == s
     const uint64_t sub_capacity = (n_blocks + n_queues - 1) / n_queues * (uint64_t)(PTR_TILE_W * rpb);
     PTR_TRY(grow(c, c->queue, (size_t)(n_queues * sub_capacity) * sizeof(uint32_t)));
     const bool odd = (c->hybrid_calls & 1u) != 0;

@@ -36,7 +36,7 @@ struct alignas(16) FrameHeader {          // 128 bytes
 static_assert(sizeof(FrameHeader) == 128, "FrameHeader layout");
 
 struct alignas(16) SphereG64 { double cx, cy, cz, r2; };            // exact geometry (Sphere.js:9-11)
-struct alignas(16) SphereM64 { double sr, sg, sb, er, eg, eb; };    // exact material (Material.js:5-10)
+struct alignas(16) SphereM64 { double sr, sg, sb, er, eg, eb, refl, transp; };   // exact material (Material.js:5-10)
 
 // float32 path: everything is relative to the (wave-uniform) camera origin, computed in
 // float64 on the host and rounded once, so a far-away camera costs no float32 precision.
@@ -59,7 +59,7 @@ struct alignas(64) SphereP32 {
     // group 3: winner refinement (per-lane gather)
     float inv_r;          // 1 / radius
     float hed;            // half the error bound of disc' = r^2 - |l x d|^2  (10 eps r |l| + 2 eps r^2)
-    float pad0, pad1;
+    float refl, transp;   // Material.reflection / .transparency (extension modes only)
 };
 static_assert(sizeof(SphereP32) == 64, "SphereP32 layout");
 // material, gathered per lane for the winning sphere; scmax/emax = largest channel
@@ -128,6 +128,8 @@ struct RenderArgs {
     uint32_t  queue_capacity;        // entries per sub-queue
     uint32_t  n_queues;
     unsigned long long* stats;       // nullable; 8 words, see ptr_stats
+    int32_t   max_depth, spp;        // extension modes (ptr_kernels_ext.hip)
+    uint32_t  seed;
 };
 
 struct TraceArgs {

@@ -14,4 +14,7 @@ hipError_t launch_trace_batch_exact(const TraceArgs& a, hipStream_t s);
 hipError_t launch_render_fast(const RenderArgs& a, int n_frames, bool hybrid, hipStream_t s);
 int fast_kernel_rows_per_block();   // image rows one workgroup of the float32 kernel covers
 
+// extension modes: reflection/refraction to max_depth, Philox-jittered spp (ptr_kernels_ext.hip)
+hipError_t launch_render_ext(const RenderArgs& a, int n_frames, bool f64, hipStream_t s);
+
 }  // namespace ptr

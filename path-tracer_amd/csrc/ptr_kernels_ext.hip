@@ -1,0 +1,232 @@
+// ptr_kernels_ext.hip — EXTENSION modes: Whitted reflection/refraction to depth N and Philox-seeded
+// multi-sample pixels.  The reference implements none of this (MAX_RAY_DEPTH is
+// never read, Material.reflection/.transparency are never used, there is no sampling), so there is
+// no reference parity to claim: the specification is the "weighted depth-first expansion" written out
+// in include/ptr.h (extension modes), and this file performs that arithmetic in that order.
+//   T = double: bit-identical to that specification (compiled with -ffp-contract=off)
+//   T = float : the throughput form, compared with it within a stated tolerance
+// With max_depth 0 and spp 1 the result equals the reference path (and ptr_kernels_exact.hip).
+#include <hip/hip_runtime.h>
+#include "ptr_device.h"
+#include "ptr_kernels.h"
+
+namespace ptr {
+
+#define PTR_EXT_MAX_DEPTH 16
+
+template <typename T> struct V { T x, y, z; };
+
+template <typename T> __device__ __forceinline__ T tsqrt(T x);
+template <> __device__ __forceinline__ double tsqrt<double>(double x) { return __builtin_sqrt(x); }
+template <> __device__ __forceinline__ float tsqrt<float>(float x) { return __builtin_sqrtf(x); }
+
+template <typename T> __device__ __forceinline__ void normalize_v(V<T>& v)
+{
+    const T len2 = v.x * v.x + v.y * v.y + v.z * v.z;      // Vector3.js:23-33
+    if (len2 > 0) {
+        const T inv = T(1) / tsqrt<T>(len2);
+        v.x *= inv; v.y *= inv; v.z *= inv;
+    }
+}
+
+// Scene access: float64 reads the exact records (absolute coordinates); float32 reads the
+// camera-relative records, whose origin is the camera (so rays start at 0 there).
+template <typename T> struct SceneT;
+template <> struct SceneT<double> {
+    FrameView fv;
+    __device__ V<double> center(int i) const { const SphereG64 g = fv.g64[i]; return V<double>{g.cx, g.cy, g.cz}; }
+    __device__ double r2(int i) const { return fv.g64[i].r2; }
+    __device__ V<double> sc(int i) const { const SphereM64& m = fv.m64[i]; return V<double>{m.sr, m.sg, m.sb}; }
+    __device__ V<double> em(int i) const { const SphereM64& m = fv.m64[i]; return V<double>{m.er, m.eg, m.eb}; }
+    __device__ double refl(int i) const { return fv.m64[i].refl; }
+    __device__ double transp(int i) const { return fv.m64[i].transp; }
+    __device__ V<double> bg() const { return V<double>{fv.h->bg64[0], fv.h->bg64[1], fv.h->bg64[2]}; }
+};
+template <> struct SceneT<float> {
+    FrameView fv;
+    __device__ V<float> center(int i) const { const SphereP32& p = fv.p32[i]; return V<float>{p.lx, p.ly, p.lz}; }
+    __device__ float r2(int i) const { return fv.p32[i].r2; }
+    __device__ V<float> sc(int i) const { const SphereM32& m = fv.m32[i]; return V<float>{m.sr, m.sg, m.sb}; }
+    __device__ V<float> em(int i) const { const SphereM32& m = fv.m32[i]; return V<float>{m.er, m.eg, m.eb}; }
+    __device__ float refl(int i) const { return fv.p32[i].refl; }
+    __device__ float transp(int i) const { return fv.p32[i].transp; }
+    __device__ V<float> bg() const { return V<float>{fv.h->bg32[0], fv.h->bg32[1], fv.h->bg32[2]}; }
+};
+
+// Sphere.intersect (Sphere.js:15-33); any_hit skips the unused sqrt of the shadow test
+template <typename T>
+__device__ __forceinline__ bool intersect_t(const V<T>& o, const V<T>& d, const V<T>& c, T r2, T& t0, T& t1, bool any_hit)
+{
+    const T lx = c.x - o.x, ly = c.y - o.y, lz = c.z - o.z;
+    const T tca = lx * d.x + ly * d.y + lz * d.z;
+    if (tca < 0) return false;
+    const T d2 = (lx * lx + ly * ly + lz * lz) - tca * tca;
+    if (d2 > r2) return false;
+    if (!any_hit) {
+        const T thc = tsqrt<T>(r2 - d2);
+        t0 = tca - thc; t1 = tca + thc;
+    }
+    return true;
+}
+
+template <typename T> struct ExtRay { V<T> o, d, w; int depth; };
+
+// weighted depth-first expansion (include/ptr.h, "extension modes")
+template <typename T>
+__device__ V<T> trace_ext(const SceneT<T>& sc, V<T> o0, V<T> d0, int max_depth)
+{
+    const int n = sc.fv.h->n, nl = sc.fv.h->n_lights;
+    ExtRay<T> stack[PTR_EXT_MAX_DEPTH + 2];
+    int top = 1;
+    stack[0] = ExtRay<T>{o0, d0, V<T>{1, 1, 1}, 0};
+    V<T> acc{0, 0, 0};
+    const V<T> bg = sc.bg();
+    while (top > 0) {
+        const ExtRay<T> r = stack[--top];
+        T tnear = T(PTR_INFINITY);
+        int e = -1;
+        for (int i = 0; i < n; i++) {
+            T t0 = T(PTR_INFINITY), t1 = T(PTR_INFINITY);
+            if (intersect_t<T>(r.o, r.d, sc.center(i), sc.r2(i), t0, t1, false)) {
+                if (t0 < 0) t0 = t1;
+                if (t0 < tnear) { tnear = t0; e = i; }
+            }
+        }
+        if (e < 0) {
+            acc.x += r.w.x * bg.x; acc.y += r.w.y * bg.y; acc.z += r.w.z * bg.z;
+            continue;
+        }
+        const V<T> em = sc.em(e), col = sc.sc(e), C = sc.center(e);
+        acc.x += r.w.x * em.x; acc.y += r.w.y * em.y; acc.z += r.w.z * em.z;
+        const V<T> P{r.o.x + r.d.x * tnear, r.o.y + r.d.y * tnear, r.o.z + r.d.z * tnear};
+        V<T> N{P.x - C.x, P.y - C.y, P.z - C.z};
+        normalize_v(N);
+        bool inside = false;
+        T dn = r.d.x * N.x + r.d.y * N.y + r.d.z * N.z;
+        if (dn > 0) { N.x = -N.x; N.y = -N.y; N.z = -N.z; inside = true; dn = -dn; }
+        const T transp = sc.transp(e), refl = sc.refl(e);
+        if ((transp > 0 || refl > 0) && r.depth < max_depth) {
+            const T facing = -dn;
+            const T f = 1 - facing;
+            const T fresnel = T(1) * T(0.1) + (f * f * f) * (T(1) - T(0.1));
+            const V<T> wsc{r.w.x * col.x, r.w.y * col.y, r.w.z * col.z};
+            if (transp > 0) {
+                const T eta = inside ? T(1.1) : T(1) / T(1.1);
+                const T cosi = -dn;
+                const T k = 1 - eta * eta * (1 - cosi * cosi);
+                if (k >= 0) {
+                    ExtRay<T>& c = stack[top++];
+                    const T g = eta * cosi - tsqrt<T>(k);
+                    const T wt = (1 - fresnel) * transp;
+                    c.o = V<T>{P.x - N.x * T(PTR_BIAS), P.y - N.y * T(PTR_BIAS), P.z - N.z * T(PTR_BIAS)};
+                    c.d = V<T>{r.d.x * eta + N.x * g, r.d.y * eta + N.y * g, r.d.z * eta + N.z * g};
+                    c.w = V<T>{wsc.x * wt, wsc.y * wt, wsc.z * wt};
+                    normalize_v(c.d);
+                    c.depth = r.depth + 1;
+                }
+            }
+            ExtRay<T>& c = stack[top++];
+            const T two = 2 * dn;
+            c.o = V<T>{P.x + N.x * T(PTR_BIAS), P.y + N.y * T(PTR_BIAS), P.z + N.z * T(PTR_BIAS)};
+            c.d = V<T>{r.d.x - N.x * two, r.d.y - N.y * two, r.d.z - N.z * two};
+            c.w = V<T>{wsc.x * fresnel, wsc.y * fresnel, wsc.z * fresnel};
+            normalize_v(c.d);
+            c.depth = r.depth + 1;
+        } else {
+            // the reference's direct lighting (RayTracer.js:60-91)
+            const V<T> so{P.x + N.x * T(PTR_BIAS), P.y + N.y * T(PTR_BIAS), P.z + N.z * T(PTR_BIAS)};
+            V<T> dif{0, 0, 0};
+            for (int kk = 0; kk < nl; kk++) {
+                const int i = sc.fv.lights[kk];
+                const V<T> Ci = sc.center(i), ei = sc.em(i);
+                V<T> L{Ci.x - P.x, Ci.y - P.y, Ci.z - P.z};
+                normalize_v(L);
+                T tr = 1;
+                for (int j = 0; j < n; j++) {
+                    if (j == i) continue;
+                    T t0, t1;
+                    if (intersect_t<T>(so, L, sc.center(j), sc.r2(j), t0, t1, true)) { tr = 0; break; }
+                }
+                T ratio = N.x * L.x + N.y * L.y + N.z * L.z;
+                ratio = (ratio != ratio) ? ratio : (ratio > 0 ? ratio : T(0));       // Math.max(0, .)
+                dif.x += (col.x * tr) * (ei.x * ratio);
+                dif.y += (col.y * tr) * (ei.y * ratio);
+                dif.z += (col.z * tr) * (ei.z * ratio);
+            }
+            acc.x += r.w.x * dif.x; acc.y += r.w.y * dif.y; acc.z += r.w.z * dif.z;
+        }
+    }
+    return acc;
+}
+
+// Philox4x32-10 (Salmon et al., SC'11); counter = (x, y, sample, 0), key = (seed, 'PTR!')
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t& r0, uint32_t& r1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    r0 = c0; r1 = c1;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(PTR_BLOCK) render_ext_kernel(RenderArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * PTR_TILE_W + wave * 8 + (lane & 7);
+    const int row = blockIdx.y * PTR_TILE_H + (lane >> 3);
+    if (x >= a.width || row >= a.scan_height) return;
+    const int frame = blockIdx.z;
+    const int y = global_y(a, row);
+    SceneT<T> sc;
+    sc.fv = frame_view(a.scenes + (uint64_t)(a.first_frame + frame) * a.frame_stride);
+
+    const T inv_w = T(a.cam.inv_w), inv_h = T(a.cam.inv_h), angle = T(a.cam.angle), aspect = T(a.cam.aspect);
+    // float32 works camera-relative: the ray starts at 0 there
+    const V<T> origin = sizeof(T) == 8 ? V<T>{T(a.cam.org[0]), T(a.cam.org[1]), T(a.cam.org[2])} : V<T>{0, 0, 0};
+    V<T> sum{0, 0, 0};
+    for (int s = 0; s < a.spp; s++) {
+        T px = T(x) + T(0.5), py = T(y) + T(0.5);
+        if (a.spp > 1) {
+            uint32_t r0, r1;
+            philox4x32_10((uint32_t)x, (uint32_t)y, (uint32_t)s, 0u, a.seed, 0x50545221u, r0, r1);
+            px = T(x) + T((double(r0) + 0.5) / 4294967296.0);
+            py = T(y) + T((double(r1) + 0.5) / 4294967296.0);
+        }
+        const T xx = (2 * (px * inv_w) - 1) * angle * aspect;      // RayTracer.js:171-172
+        const T yy = (1 - 2 * (py * inv_h)) * angle;
+        V<T> d;
+        if (a.cam.general) {
+            d.x = xx * T(a.cam.right[0]) + yy * T(a.cam.up[0]) + T(a.cam.fwd[0]);
+            d.y = xx * T(a.cam.right[1]) + yy * T(a.cam.up[1]) + T(a.cam.fwd[1]);
+            d.z = xx * T(a.cam.right[2]) + yy * T(a.cam.up[2]) + T(a.cam.fwd[2]);
+        } else {
+            d = V<T>{xx, yy, T(-1)};
+        }
+        normalize_v(d);
+        const V<T> c = trace_ext<T>(sc, origin, d, a.max_depth);
+        sum.x += c.x; sum.y += c.y; sum.z += c.z;
+    }
+    if (a.spp > 1) { const T k = T(a.spp); sum.x /= k; sum.y /= k; sum.z /= k; }
+    const uint64_t at = frame * a.out_frame_stride + (uint64_t)a.width * row + x;
+    a.out8[at] = pack_js((double)sum.x, (double)sum.y, (double)sum.z);
+    if (a.out32f) {
+        float* p = a.out32f + 4 * at;
+        p[0] = (float)sum.x; p[1] = (float)sum.y; p[2] = (float)sum.z; p[3] = 1.0f;
+    }
+}
+
+hipError_t launch_render_ext(const RenderArgs& a, int n_frames, bool f64, hipStream_t s)
+{
+    dim3 grid((a.width + PTR_TILE_W - 1) / PTR_TILE_W, (a.scan_height + PTR_TILE_H - 1) / PTR_TILE_H, n_frames);
+    if (f64) hipLaunchKernelGGL(render_ext_kernel<double>, grid, dim3(PTR_BLOCK), 0, s, a);
+    else     hipLaunchKernelGGL(render_ext_kernel<float>, grid, dim3(PTR_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace ptr

@@ -409,7 +409,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
             if (unsure[p].any()) {
                 // one counter word would saturate (~88 returning atomics/us chip-wide): the queue is
                 // cut into n_queues sub-queues, each with its own counter line, chosen by workgroup
-                const uint32_t sub = bid % a.n_queues;
+                const uint32_t sub = bid & (a.n_queues - 1u);       // n_queues is a power of two
                 const uint32_t q = atomicAdd(a.counter + sub * PTR_COUNTER_STRIDE, 1u);
                 if (q < a.queue_capacity)
                     a.queue[(uint64_t)sub * a.queue_capacity + q] = (uint32_t)(frame * frame_px + (uint64_t)a.width * r.row + r.x);

@@ -206,8 +206,9 @@ class Renderer:
         return Params(width, height, start_y, height if scan_height is None else scan_height,
                       max_depth, spp, seed, flags)
 
-    def render(self, width, height, start_y=0, scan_height=None, flags=QUIRK_ROW_SHIFT, want_f32=False):
-        p = self.params(width, height, start_y, scan_height, flags)
+    def render(self, width, height, start_y=0, scan_height=None, flags=QUIRK_ROW_SHIFT, want_f32=False,
+               max_depth=0, spp=1, seed=0):
+        p = self.params(width, height, start_y, scan_height, flags, max_depth, spp, seed)
         out = np.empty(p.width * p.scan_height, dtype=np.uint32)
         f32 = np.empty((p.scan_height, p.width, 4), dtype=np.float32) if want_f32 else None
         self._check(self._L.ptr_render(self._h, C.byref(p), out.ctypes.data_as(C.POINTER(C.c_uint32)),

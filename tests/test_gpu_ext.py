@@ -1,0 +1,129 @@
+"""GPU tests of the EXTENSION modes (max_depth > 0: reflection/refraction; spp > 1: Philox jitter),
+through the C ABI.  The reference implements neither, so the bar is the float64 specification
+(oracle/ptr_oracle.c orc_render_ext, self-pinned by tests/golden/ext — "parity unpinned"):
+  PTR_MODE_EXACT_F64: identical bytes;
+  float32 (every other mode): per-channel error <= 1/255 except on at most 0.5 % of the pixels
+  (discontinuities: silhouettes, shadow edges and their mirror images), and PSNR >= 40 dB."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle_py as orc          # noqa: E402  (checker only)
+import ptr_amd                   # noqa: E402
+
+X = ptr_amd.MODE_EXACT_F64
+
+
+@pytest.fixture(scope="module")
+def rdr():
+    r = ptr_amd.Renderer(0)
+    yield r
+    r.close()
+
+
+def _load(r, sc):
+    r.set_camera(None)
+    r.set_elements(sc["elements"])
+    r.set_background(sc["background"])
+
+
+def _index(golden_dir):
+    with open(os.path.join(golden_dir, "ext", "index.json")) as f:
+        return json.load(f)["cases"]
+
+
+def test_exact_matches_frozen_vectors(rdr, golden_dir, scenes):
+    for key, c in _index(golden_dir).items():
+        _load(rdr, scenes[c["scene"]])
+        got = rdr.render(c["width"], c["height"], flags=X, max_depth=c["max_depth"], spp=c["spp"], seed=c["seed"])
+        assert hashlib.sha256(got.tobytes()).hexdigest() == c["sha256"], key
+        if "file" in c:
+            want = np.fromfile(os.path.join(golden_dir, c["file"]), dtype=np.uint32)
+            assert np.array_equal(got, want), key
+
+
+@pytest.mark.parametrize("name,depth,spp", [("random_2", 5, 1), ("random_4", 4, 2), ("random_7", 2, 1),
+                                            ("light_below_horizon", 5, 3), ("empty", 5, 2),
+                                            ("coincident", 5, 1), ("odd_colours", 2, 2)])
+def test_exact_matches_specification(rdr, scenes, name, depth, spp):
+    sc = scenes[name]
+    _load(rdr, sc)
+    got = rdr.render(128, 96, flags=X, max_depth=depth, spp=spp, seed=42)
+    want = orc.render_ext(orc.scene_to_soa(sc["elements"]), sc["background"], 128, 96,
+                          max_depth=depth, spp=spp, seed=42)
+    bad = np.flatnonzero(got != want)
+    assert bad.size == 0, f"{name}: {bad.size} pixels differ, first {bad[:5]}"
+
+
+def test_exact_bands_tile_the_frame(rdr, scenes):
+    sc = scenes["example1"]
+    _load(rdr, sc)
+    full = rdr.render(200, 150, flags=X, max_depth=5, spp=2, seed=3).reshape(150, 200)
+    parts = [rdr.render(200, 150, y0, h, flags=X, max_depth=5, spp=2, seed=3).reshape(h, 200)
+             for y0, h in ((0, 1), (1, 70), (71, 79))]
+    assert np.array_equal(full, np.vstack(parts))
+
+
+def test_exact_general_camera_rgb32f(rdr, scenes):
+    # out_rgba32f carries the unclamped mean colour; moved camera == moved scene
+    sc = scenes["example1"]
+    soa = orc.scene_to_soa(sc["elements"])
+    _load(rdr, sc)
+    rdr.set_camera(origin=(0.5, 0.25, 2.0))
+    got, f32 = rdr.render(96, 64, flags=X, max_depth=3, want_f32=True)
+    rdr.set_camera(None)
+    _, ref64 = orc.render_ext(soa, sc["background"], 96, 64, max_depth=3, want_rgb64=True)
+    assert np.isfinite(f32).all() and f32[..., 3].min() == 1.0
+    moved = soa.copy()
+    moved[0] -= 0.5; moved[1] -= 0.25; moved[2] -= 2.0
+    _, want64 = orc.render_ext(moved, sc["background"], 96, 64, max_depth=3, want_rgb64=True)
+    assert np.abs(f32[..., :3] - want64).max() < 1e-3          # translation in f64: tiny rounding only
+    assert not np.allclose(want64, ref64)
+
+
+def _psnr(a, b):
+    a8 = a.view(np.uint8).reshape(-1, 4)[:, :3].astype(np.float64)
+    b8 = b.view(np.uint8).reshape(-1, 4)[:, :3].astype(np.float64)
+    mse = ((a8 - b8) ** 2).mean()
+    return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+
+
+@pytest.mark.parametrize("flags", [0, ptr_amd.MODE_F32_ONLY])
+@pytest.mark.parametrize("name,w,h,depth,spp", [("example1", 640, 480, 5, 1), ("example1", 320, 240, 5, 4),
+                                                ("random_3", 320, 240, 5, 1), ("random_5", 320, 240, 3, 2)])
+def test_float32_within_tolerance(rdr, scenes, name, w, h, depth, spp, flags):
+    sc = scenes[name]
+    _load(rdr, sc)
+    got = rdr.render(w, h, flags=flags, max_depth=depth, spp=spp, seed=11)
+    want = orc.render_ext(orc.scene_to_soa(sc["elements"]), sc["background"], w, h,
+                          max_depth=depth, spp=spp, seed=11)
+    d = np.abs(got.view(np.uint8).astype(np.int16) - want.view(np.uint8).astype(np.int16)).reshape(-1, 4).max(axis=1)
+    off = int((d > 1).sum())
+    print(f"{name} d{depth} s{spp}: {int((d > 0).sum())} px differ, {off} by more than 1/255, "
+          f"PSNR {_psnr(got, want):.1f} dB")
+    assert off <= 0.005 * d.size
+    assert _psnr(got, want) >= 40.0
+
+
+def test_full_hd_depth5_hash(rdr, golden_dir, scenes):
+    c = _index(golden_dir)["example1@1920x1080_d5_s1_k0"]
+    _load(rdr, scenes["example1"])
+    got = rdr.render(1920, 1080, flags=X, max_depth=5)
+    assert hashlib.sha256(got.tobytes()).hexdigest() == c["sha256"]
+
+
+def test_rejections(rdr, scenes):
+    _load(rdr, scenes["example1"])
+    for kw, code in ((dict(max_depth=17), ptr_amd.ERR_INVALID), (dict(max_depth=-1), ptr_amd.ERR_INVALID),
+                     (dict(spp=0), ptr_amd.ERR_INVALID),
+                     (dict(max_depth=2, flags=ptr_amd.QUIRK_ROW_SHIFT), ptr_amd.ERR_INVALID),
+                     (dict(spp=2, flags=ptr_amd.FLAG_STATS), ptr_amd.ERR_UNSUPPORTED)):
+        kw.setdefault("flags", 0)
+        with pytest.raises(ptr_amd.PtrError) as e:
+            rdr.render(64, 48, **kw)
+        assert e.value.code == code, kw

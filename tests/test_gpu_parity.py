@@ -279,11 +279,11 @@ def test_errors(scenes):
         with pytest.raises(ptr_amd.PtrError) as e:
             r.render(8, 8, flags=ptr_amd.MODE_EXACT_F64 | ptr_amd.MODE_F32_ONLY)
         assert e.value.code == ptr_amd.ERR_INVALID
-        p = r.params(8, 8, max_depth=3)
+        p = r.params(8, 8, max_depth=17)
         out = np.empty(64, dtype=np.uint32)
         import ctypes as C
         rc = ptr_amd.lib().ptr_render(r._h, C.byref(p), out.ctypes.data_as(C.POINTER(C.c_uint32)), None)
-        assert rc == ptr_amd.ERR_UNSUPPORTED
+        assert rc == ptr_amd.ERR_INVALID
         with pytest.raises(ptr_amd.PtrError):
             ptr_amd.Renderer(99)
     finally:
