@@ -80,6 +80,20 @@ static int get_args(napi_env env, napi_callback_info info, size_t want, napi_val
     return 1;
 }
 
+/* at least `want`, at most `max` arguments; missing optional ones are left as undefined */
+static int get_args_opt(napi_env env, napi_callback_info info, size_t want, size_t max, napi_value *argv)
+{
+    size_t argc = max;
+    napi_value undef;
+    if (napi_get_undefined(env, &undef) != napi_ok) return 0;
+    for (size_t k = 0; k < max; k++) argv[k] = undef;
+    if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < want) {
+        napi_throw_type_error(env, NULL, "wrong number of arguments");
+        return 0;
+    }
+    return 1;
+}
+
 static int get_i32(napi_env env, napi_value v, int32_t *out)
 {
     if (napi_get_value_int32(env, v, out) != napi_ok) {
@@ -208,6 +222,16 @@ static int read_params(napi_env env, napi_value *argv, ptr_params *p)
         return 0;
     p->flags = (uint32_t)flags;
     p->spp = 1;
+    /* optional: maxDepth, spp, seed (extension modes; include/ptr.h) */
+    napi_valuetype t;
+    if (napi_typeof(env, argv[5], &t) == napi_ok && t != napi_undefined && !get_i32(env, argv[5], &p->max_depth)) return 0;
+    if (napi_typeof(env, argv[6], &t) == napi_ok && t != napi_undefined && !get_i32(env, argv[6], &p->spp)) return 0;
+    if (napi_typeof(env, argv[7], &t) == napi_ok && t != napi_undefined) {
+        if (napi_get_value_uint32(env, argv[7], &p->seed) != napi_ok) {
+            napi_throw_type_error(env, NULL, "seed must be an unsigned 32-bit integer");
+            return 0;
+        }
+    }
     return 1;
 }
 
@@ -224,8 +248,8 @@ static int check_frame_size(napi_env env, const ptr_params *p)
 
 static napi_value js_render(napi_env env, napi_callback_info info)
 {
-    napi_value argv[6];
-    if (!get_args(env, info, 6, argv)) return NULL;
+    napi_value argv[9];
+    if (!get_args_opt(env, info, 6, 9, argv)) return NULL;
     ptr_ctx *ctx = get_ctx(env, argv[0]);
     if (!ctx) return NULL;
     ptr_params p;
@@ -291,8 +315,8 @@ static void render_complete(napi_env env, napi_status status, void *data)
 
 static napi_value js_render_async(napi_env env, napi_callback_info info)
 {
-    napi_value argv[6];
-    if (!get_args(env, info, 6, argv)) return NULL;
+    napi_value argv[9];
+    if (!get_args_opt(env, info, 6, 9, argv)) return NULL;
     ptr_ctx *ctx = get_ctx(env, argv[0]);
     if (!ctx) return NULL;
     render_job *j = (render_job *)calloc(1, sizeof *j);

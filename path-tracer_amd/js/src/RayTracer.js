@@ -21,6 +21,12 @@ import native from './native.js';
  *   hybrid (default): float32 kernel + float64 re-trace of uncertain pixels; bytes equal the reference
  *   exact: every pixel in float64, operation for operation
  *   f32: float32 only (max per-channel error 1/255 except on silhouettes / shadow edges)
+ *
+ * Extension modes (NOT reference behaviour: the reference stores Material.reflection/.transparency
+ * and MAX_RAY_DEPTH but never reads them): renderFrame(w, h, {maxDepth, spp, seed}) follows
+ * reflection/refraction rays to maxDepth (<= 16) and averages spp Philox-jittered samples per pixel.
+ * Their specification is in include/ptr.h; mode 'exact' renders it in float64 bit for bit, every
+ * other mode in float32.  render() itself always has the reference semantics.
  */
 export default class RayTracer {
     constructor(backgroundColor, scene, camera, options = {}) {
@@ -100,11 +106,30 @@ export default class RayTracer {
         return this._native.renderAsync(this._handle, d[0], d[1], d[2], d[3], this._native.QUIRK_ROW_SHIFT | this._modeFlags);
     }
 
-    /** Every row at its true position.  options: {startY, scanHeight, useCamera} */
+    static _ext(options) {
+        const maxDepth = options.maxDepth === undefined ? 0 : options.maxDepth;
+        const spp = options.spp === undefined ? 1 : options.spp;
+        const seed = options.seed === undefined ? 0 : options.seed;
+        if (!Number.isInteger(maxDepth) || maxDepth < 0 || maxDepth > 16) throw new RangeError('maxDepth must be an integer in [0, 16]');
+        if (!Number.isInteger(spp) || spp < 1 || spp > 65536) throw new RangeError('spp must be an integer in [1, 65536]');
+        if (!Number.isInteger(seed) || seed < 0 || seed > 0xffffffff) throw new RangeError('seed must be an unsigned 32-bit integer');
+        return [maxDepth, spp, seed];
+    }
+
+    /** Every row at its true position.  options: {startY, scanHeight, useCamera, maxDepth, spp, seed} */
     renderFrame(width, height, options = {}) {
         const d = RayTracer._dims(width, height, options.startY, options.scanHeight);
+        const e = RayTracer._ext(options);
         this._upload(!!options.useCamera);
-        return this._native.render(this._handle, d[0], d[1], d[2], d[3], this._modeFlags);
+        return this._native.render(this._handle, d[0], d[1], d[2], d[3], this._modeFlags, e[0], e[1], e[2]);
+    }
+
+    /** Promise<ArrayBuffer> form of renderFrame(). */
+    renderFrameAsync(width, height, options = {}) {
+        const d = RayTracer._dims(width, height, options.startY, options.scanHeight);
+        const e = RayTracer._ext(options);
+        this._upload(!!options.useCamera);
+        return this._native.renderAsync(this._handle, d[0], d[1], d[2], d[3], this._modeFlags, e[0], e[1], e[2]);
     }
 
     /** Many rays at once: Float64Array origins (or null = (0,0,0)) and dirs, 3 numbers per ray. */

@@ -174,6 +174,30 @@ async function gpuTests() {
         assert.ok(plain.subarray((h - 1) * w).some(v => v !== 0));
         rt.dispose();
     });
+    await atest('extension modes: renderFrame({maxDepth, spp, seed}) equals the frozen specification vectors', async () => {
+        // NOT reference parity (the reference has no bounce loop and no sampling): tests/golden/ext holds
+        // outputs of the float64 specification, which mode 'exact' reproduces bit for bit
+        const ext = JSON.parse(fs.readFileSync(path.join(golden, 'ext', 'index.json'))).cases;
+        const rt = new RayTracer(new Vector3(2, 2, 2), buildExample1(), undefined, { mode: 'exact' });
+        for (const key of ['example1@160x120_d5_s1_k0', 'example1@160x120_d5_s4_k7', 'example1@160x120_d0_s4_k7']) {
+            const c = ext[key];
+            const got = new Uint8Array(rt.renderFrame(c.width, c.height, { maxDepth: c.max_depth, spp: c.spp, seed: c.seed }));
+            assert.ok(sameBytes(got, u8(c.file)), key);
+        }
+        const c = ext['example1@160x120_d5_s4_k7'];
+        const viaPromise = new Uint8Array(await rt.renderFrameAsync(c.width, c.height, { maxDepth: 5, spp: 4, seed: 7 }));
+        assert.ok(sameBytes(viaPromise, u8(c.file)));
+        assert.ok(sameBytes(new Uint8Array(rt.renderFrame(64, 48, { maxDepth: 0, spp: 1 })), new Uint8Array(rt.renderFrame(64, 48))));
+        assert.throws(() => rt.renderFrame(64, 48, { maxDepth: 17 }), RangeError);
+        assert.throws(() => rt.renderFrame(64, 48, { spp: 0 }), RangeError);
+        rt.dispose();
+        const f32 = new RayTracer(new Vector3(2, 2, 2), buildExample1());
+        const a = new Uint8Array(f32.renderFrame(c.width, c.height, { maxDepth: 5, spp: 4, seed: 7 })), b = u8(c.file);
+        let off = 0;
+        for (let i = 0; i < a.length; i++) if (Math.abs(a[i] - b[i]) > 1) off++;
+        assert.ok(off <= 0.005 * a.length, `float32: ${off} bytes off by more than 1/255`);
+        f32.dispose();
+    });
     test('argument validation', () => {
         const rt = new RayTracer(new Vector3(2, 2, 2), buildExample1());
         assert.throws(() => rt.render(0, 10), RangeError);
