@@ -53,6 +53,9 @@ extern "C" {
  * the reasons the hybrid mode would re-trace the pixel (1 hit/miss band, 2 origin on a surface,
  * 4 nearest-vs-second ordering, 8 far clip, 16 shadow band, 32 rounding band).               */
 #define PTR_DEBUG_REASONS     0x8000u
+/* Diagnostics/tests: use the many-sphere float32 kernel (sphere list staged through LDS, chosen by
+ * itself above 128 spheres) whatever the sphere count.  Same results contract as the default.     */
+#define PTR_DEBUG_FORCE_MANY  0x4000u
 
 typedef struct ptr_ctx ptr_ctx;
 
@@ -116,6 +119,8 @@ typedef struct ptr_stats {
     uint64_t exit_d2;       /* ... at d2>radius2                          (RT/src/Sphere.js:23) */
     uint64_t exit_hit;      /* ... returning true                         (RT/src/Sphere.js:32) */
     uint64_t retraced;      /* hybrid mode: pixels re-traced in float64 (last call, always set) */
+    uint64_t reshaded;      /* hybrid mode: pixels whose nearest element was certain and only the
+                               shading was redone in float64 (last call, always set)            */
 } ptr_stats;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */

@@ -367,32 +367,34 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
         if (timing) { HIP_TRY(c, hipEventRecord(c->ev[1], s)); c->timed_kernels = 1; }
         return PTR_OK;
     }
+    const bool many = c->n_spheres > PTR_MANY_THRESHOLD || (p->flags & PTR_DEBUG_FORCE_MANY);
     if (p->flags & PTR_MODE_F32_ONLY) {
-        HIP_TRY(c, launch_render_fast(a, n_frames, false, s));
+        HIP_TRY(c, many ? launch_render_many(a, n_frames, false, s) : launch_render_fast(a, n_frames, false, s));
         if (timing) { HIP_TRY(c, hipEventRecord(c->ev[1], s)); c->timed_kernels = 1; }
         return PTR_OK;
     }
     // hybrid: float32 kernel fills the sub-queues, float64 kernel drains them
-    const int rpb = fast_kernel_rows_per_block();
+    const int rpb = many ? many_kernel_rows_per_block() : fast_kernel_rows_per_block();
     const uint64_t n_blocks = (uint64_t)((p->width + PTR_TILE_W - 1) / PTR_TILE_W) *
                               (uint64_t)((p->scan_height + rpb - 1) / rpb) * (uint64_t)n_frames;
     uint64_t n_queues = 1;                                     // a power of two (the kernel masks)
     while (n_queues * 2 <= PTR_MAX_QUEUES && n_queues * 8 <= n_blocks) n_queues *= 2;
     // a workgroup can queue at most PTR_BLOCK pixels; sub-queue s serves the workgroups b with (b & (n_queues - 1)) == s
     const uint64_t sub_capacity = (n_blocks + n_queues - 1) / n_queues * (uint64_t)(PTR_TILE_W * rpb);
-    PTR_TRY(grow(c, c->queue, (size_t)(n_queues * sub_capacity) * sizeof(uint32_t)));
+    PTR_TRY(grow(c, c->queue, (size_t)(n_queues * sub_capacity) * 3 * sizeof(uint32_t)));   // ids + 2 info words
     const bool odd = (c->hybrid_calls & 1u) != 0;
     a.queue = static_cast<uint32_t*>(c->queue.ptr);
+    a.qinfo = a.queue + n_queues * sub_capacity;
     a.queue_capacity = (uint32_t)sub_capacity;
     a.n_queues = (uint32_t)n_queues;
     a.counter = reinterpret_cast<uint32_t*>(words + (odd ? WORDS_COUNTER_B : WORDS_COUNTER_A));
     a.counter_next = reinterpret_cast<uint32_t*>(words + (odd ? WORDS_COUNTER_A : WORDS_COUNTER_B));
     c->hybrid_calls++;
     HIP_TRY(c, hipMemsetAsync(words + WORDS_STATS, 0, 256, s));
-    hipError_t e = launch_render_fast(a, n_frames, true, s);
+    hipError_t e = many ? launch_render_many(a, n_frames, true, s) : launch_render_fast(a, n_frames, true, s);
     if (e == hipSuccess && timing) e = hipEventRecord(c->ev[1], s);
     if (e == hipSuccess) {
-        e = launch_retrace_exact(a, s);
+        e = launch_retrace_exact(a, many ? 8 : 1, s);
         if (e == hipSuccess && timing) { e = hipEventRecord(c->ev[2], s); c->timed_kernels = 2; }
     }
     if (e != hipSuccess) {
@@ -714,7 +716,7 @@ int ptr_get_stats(ptr_ctx* c, ptr_stats* out)
     unsigned long long w[8];
     HIP_TRY(c, hipMemcpy(w, static_cast<unsigned char*>(c->words.ptr) + WORDS_STATS, sizeof w, hipMemcpyDeviceToHost));
     out->primary = w[0]; out->hits = w[1]; out->shadow_rays = w[2];
-    out->exit_tca = w[3]; out->exit_d2 = w[4]; out->exit_hit = w[5]; out->retraced = w[6];
+    out->exit_tca = w[3]; out->exit_d2 = w[4]; out->exit_hit = w[5]; out->retraced = w[6]; out->reshaded = w[7];
     return PTR_OK;
 }
 

@@ -17,6 +17,7 @@
 #define PTR_FAST_PPL 2            // pixels per lane in the float32 kernel (wave tile 8 x 16)
 #define PTR_MAX_QUEUES 1024       // sub-queues of the hybrid mode's re-trace queue
 #define PTR_MAX_PAIR_LIGHTS 64     // lights with a shadow pre-filter table (more lights: no culling for them)
+#define PTR_MANY_THRESHOLD 128     // more spheres than this: the LDS-staged kernel (ptr_kernels_many.hip)
 #define PTR_COUNTER_STRIDE 16     // uint32 words between two sub-queue counters (64 B)
 
 namespace ptr {
@@ -122,12 +123,15 @@ struct RenderArgs {
     CameraF32  camf;
     uint32_t* out8;                  // n_frames * width * scan_height
     float*    out32f;                // nullable, n_frames * width * scan_height * 4
-    uint32_t* queue;                 // hybrid: n_queues sub-queues of global pixel ids to re-trace
-    uint32_t* counter;               // hybrid: sub-queue fills (this call's set), PTR_COUNTER_STRIDE apart
+    uint32_t* queue;                 // hybrid: n_queues sub-queues of global pixel ids: full re-traces fill a
+                                     //   sub-queue from its front, shading-only entries from its back
+    uint32_t* qinfo;                 // hybrid: 2 words per queue slot (nearest element, light verdict codes)
+    uint32_t* counter;               // hybrid: sub-queue fills (this call's set), PTR_COUNTER_STRIDE apart;
+                                     //   word 0 = full re-traces, word 1 = shading-only entries
     uint32_t* counter_next;          // hybrid: the other set, zeroed by the re-trace for the next call
     uint32_t  queue_capacity;        // entries per sub-queue
     uint32_t  n_queues;
-    unsigned long long* stats;       // nullable; 8 words, see ptr_stats
+    unsigned long long* stats;       // 8 words, see ptr_stats
     int32_t   max_depth, spp;        // extension modes (ptr_kernels_ext.hip)
     uint32_t  seed;
 };

@@ -1,0 +1,75 @@
+// ptr_fast_common.h — pieces shared by the float32 kernels (ptr_kernels_fast.hip: few spheres, records in
+// SGPRs; ptr_kernels_many.hip: many spheres, records staged through LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ptr_device.h"
+
+namespace ptr {
+
+// ---- error-bound constants (EPS = float32 unit roundoff 2^-24) ----------------------------
+constexpr float EPS = 5.9604644775390625e-08f;
+constexpr float FAR_UNSURE = 9.0e7f;     // anything this close to the 1e8 far clip is re-traced
+
+struct F3 { float x, y, z; };
+
+// Scene data is read-only for the whole launch: typing it as the constant address space makes
+// every wave-uniform read a scalar load whatever stores the kernel has issued before.  The
+// record loads are volatile so that the compiler keeps them where they are written (it otherwise
+// sinks them next to their first use, which serialises load latency and compute).
+#define PTR_CONST __attribute__((address_space(4)))
+typedef const SphereM32 PTR_CONST* ConstM32;
+typedef const FrameHeader PTR_CONST* ConstHeader;
+typedef const int32_t PTR_CONST* ConstI32;
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef const volatile f4 PTR_CONST* ConstF4;      // a SphereP32 record = 4 x f4
+
+// the 12 leading floats of a SphereP32 record (see ptr_device.h for the field names)
+struct P32Q { f4 g0, g1, g2; };
+__device__ __forceinline__ P32Q load_p32(ConstF4 rec) { return P32Q{rec[0], rec[1], rec[2]}; }
+// the 8 leading floats (shadow test) + the (light, element) pre-filter record
+struct P32H { f4 g0, g1, pa; };
+__device__ __forceinline__ P32H load_p32h(ConstF4 rec, ConstF4 pair) { return P32H{rec[0], rec[1], pair[0]}; }
+// Scalar loads return out of order, so the only wait is "all of them": make the wave wait for the
+// record it is about to use BEFORE it requests the next one.  arrive() is an empty asm that
+// consumes every word of the record: that forces the wait here, and it keeps words the compute
+// never reads (each loop uses a subset of the record) allocated until the load has landed —
+// otherwise the register allocator hands them out while the load is in flight and the hardware
+// hazard check stalls the wave right behind the load.
+// arrive_after() also takes a value the preceding compute produces, which pins the wait AFTER that
+// compute (an asm is otherwise free to float up to just behind the loads, which hides nothing).
+#define PTR_F4_IN(v) "s"((v).x), "s"((v).y), "s"((v).z), "s"((v).w)
+__device__ __forceinline__ void arrive(const P32Q& q)
+{ asm volatile("" ::PTR_F4_IN(q.g0), PTR_F4_IN(q.g1), PTR_F4_IN(q.g2)); }
+__device__ __forceinline__ void arrive_after(const P32Q& q, float dep)
+{ asm volatile("" ::PTR_F4_IN(q.g0), PTR_F4_IN(q.g1), PTR_F4_IN(q.g2), "v"(dep)); }
+__device__ __forceinline__ void arrive(const P32H& q)
+{ asm volatile("" ::PTR_F4_IN(q.g0), PTR_F4_IN(q.g1), PTR_F4_IN(q.pa)); }
+__device__ __forceinline__ void arrive_after(const P32H& q, unsigned long long dep)
+{ asm volatile("" ::PTR_F4_IN(q.g0), PTR_F4_IN(q.g1), PTR_F4_IN(q.pa), "s"(dep)); }
+
+__device__ __forceinline__ float dot3(F3 a, F3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ unsigned long long ballot(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+__device__ __forceinline__ bool lane_of(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
+// why a pixel was queued (debug build of the kernel only: PTR_DEBUG_REASONS)
+enum : unsigned { WHY_PRIMARY = 1, WHY_CC = 2, WHY_ORDER = 4, WHY_FAR = 8, WHY_SHADOW = 16, WHY_ROUND = 32 };
+
+// NB: lane masks are wave-uniform values; they may only be updated in wave-uniform control flow
+// (never inside an exec-masked block), or the compiler turns them into per-lane values.
+template <bool DBG> struct Unsure;
+template <> struct Unsure<false> {
+    unsigned long long mask = 0ull;
+    __device__ __forceinline__ void add_mask(unsigned long long m, unsigned) { mask |= m; }
+    __device__ __forceinline__ bool any() const { return lane_of(mask); }
+    __device__ __forceinline__ unsigned why() const { return 0u; }
+};
+template <> struct Unsure<true> {
+    unsigned bits = 0u;
+    __device__ __forceinline__ void add_mask(unsigned long long m, unsigned bit) { bits |= lane_of(m) ? bit : 0u; }
+    __device__ __forceinline__ bool any() const { return bits != 0u; }
+    __device__ __forceinline__ unsigned why() const { return bits; }
+};
+
+}  // namespace ptr

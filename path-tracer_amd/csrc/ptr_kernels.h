@@ -7,12 +7,16 @@ namespace ptr {
 
 // float64, op-for-op the reference (ptr_kernels_exact.hip)
 hipError_t launch_render_exact(const RenderArgs& a, int n_frames, bool stats, hipStream_t s);
-hipError_t launch_retrace_exact(const RenderArgs& a, hipStream_t s);
+hipError_t launch_retrace_exact(const RenderArgs& a, int split, hipStream_t s);   // split: workgroups per sub-queue
 hipError_t launch_trace_batch_exact(const TraceArgs& a, hipStream_t s);
 
 // float32 with uncertainty filter (ptr_kernels_fast.hip); hybrid = queue unsure pixels
 hipError_t launch_render_fast(const RenderArgs& a, int n_frames, bool hybrid, hipStream_t s);
 int fast_kernel_rows_per_block();   // image rows one workgroup of the float32 kernel covers
+
+// float32 for many spheres: sphere list staged through LDS, two-level tests (ptr_kernels_many.hip)
+hipError_t launch_render_many(const RenderArgs& a, int n_frames, bool hybrid, hipStream_t s);
+int many_kernel_rows_per_block();
 
 // extension modes: reflection/refraction to max_depth, Philox-jittered spp (ptr_kernels_ext.hip)
 hipError_t launch_render_ext(const RenderArgs& a, int n_frames, bool f64, hipStream_t s);

@@ -28,7 +28,7 @@ __device__ __forceinline__ void normalize_js(V3& v)
 struct ExactHit { int element; double tnear; V3 P, N; };
 
 // stats word indices (match ptr_stats in include/ptr.h)
-enum { ST_PRIMARY = 0, ST_HITS, ST_SHADOW, ST_EXIT_TCA, ST_EXIT_D2, ST_EXIT_HIT, ST_RETRACED };
+enum { ST_PRIMARY = 0, ST_HITS, ST_SHADOW, ST_EXIT_TCA, ST_EXIT_D2, ST_EXIT_HIT, ST_RETRACED, ST_RESHADED };
 
 // Per-lane event counters (registers); a workgroup adds them up in LDS and issues one global
 // atomic per counter (per-lane global atomics on six words took 186 ms for one 1080p frame).
@@ -38,6 +38,63 @@ template <bool STATS>
 __device__ __forceinline__ void count(Counts* cnt, int which)
 {
     if constexpr (STATS) cnt->c[which]++;
+}
+
+// The part of RayTracer.trace after the nearest-hit search (RayTracer.js:48-93): hit frame, every
+// emissive element with its binary shadow, emission.  HINT: `codes` carries a verdict the float32 kernel
+// is certain of for each of the first 16 lights (2 bits: 0 lit or facing away, 1 blocked, 2 not certain);
+// only "not certain" lights run their occluder loop.
+template <bool STATS, bool HINT>
+__device__ __forceinline__ V3 shade_exact(const FrameView& fv, V3 o, V3 d, int element, double tnear,
+                                          uint32_t codes, ExactHit* hit, Counts* stats)
+{
+    const int n = fv.h->n;
+    // hit frame (RayTracer.js:48-58, Sphere.js:47-51)
+    const SphereG64 se = fv.g64[element];              // per-lane gather
+    const SphereM64 me = fv.m64[element];
+    V3 P{o.x + d.x * tnear, o.y + d.y * tnear, o.z + d.z * tnear};
+    V3 N{P.x - se.cx, P.y - se.cy, P.z - se.cz};
+    normalize_js(N);
+    if (d.x * N.x + d.y * N.y + d.z * N.z > 0) { N.x = -N.x; N.y = -N.y; N.z = -N.z; }
+    if (hit) { hit->P = P; hit->N = N; }
+
+    // shadow-ray origin (RayTracer.js:77, recomputed per j there; same value)
+    const V3 so{P.x + N.x * PTR_BIAS, P.y + N.y * PTR_BIAS, P.z + N.z * PTR_BIAS};
+
+    // every emissive element, scene order (RayTracer.js:61-91)
+    V3 acc{0, 0, 0};
+    const int nl = fv.h->n_lights;
+    for (int k = 0; k < nl; k++) {
+        const int i = fv.lights[k];
+        const SphereG64 li = fv.g64[i];
+        const SphereM64 lm = fv.m64[i];
+        count<STATS>(stats, ST_SHADOW);
+        V3 L{li.cx - P.x, li.cy - P.y, li.cz - P.z};
+        normalize_js(L);
+        double tr = 1.0;
+        const uint32_t code = !HINT ? 2u : (k < 16 ? (codes >> (2 * k)) & 3u : 2u);
+        if (code == 1u) tr = 0.0;
+        if (code >= 2u) {
+            for (int j = 0; j < n; j++) {
+                if (j == i) continue;
+                const SphereG64 s = fv.g64[j];
+                double lx = s.cx - so.x, ly = s.cy - so.y, lz = s.cz - so.z;
+                double tca = lx * L.x + ly * L.y + lz * L.z;
+                if (tca < 0) { count<STATS>(stats, ST_EXIT_TCA); continue; }
+                double d2 = (lx * lx + ly * ly + lz * lz) - tca * tca;
+                if (d2 > s.r2) { count<STATS>(stats, ST_EXIT_D2); continue; }
+                count<STATS>(stats, ST_EXIT_HIT);
+                tr = 0.0;                                  // any hit blocks; distance ignored (F7)
+                break;
+            }
+        }
+        double ratio = js_max0(N.x * L.x + N.y * L.y + N.z * L.z);
+        acc.x += (me.sr * tr) * (lm.er * ratio);       // RayTracer.js:89
+        acc.y += (me.sg * tr) * (lm.eg * ratio);
+        acc.z += (me.sb * tr) * (lm.eb * ratio);
+    }
+    acc.x += me.er; acc.y += me.eg; acc.z += me.eb;    // RayTracer.js:93
+    return acc;
 }
 
 // RayTracer.trace (RayTracer.js:18-95).  o, d: ray; returns unclamped colour.
@@ -69,49 +126,21 @@ __device__ V3 trace_exact(const FrameView& fv, V3 o, V3 d, ExactHit* hit, Counts
         return V3{fv.h->bg64[0], fv.h->bg64[1], fv.h->bg64[2]};
     }
     count<STATS>(stats, ST_HITS);
+    return shade_exact<STATS, false>(fv, o, d, element, tnear, 0u, hit, stats);
+}
 
-    // hit frame (RayTracer.js:48-58, Sphere.js:47-51)
-    const SphereG64 se = fv.g64[element];              // per-lane gather
-    const SphereM64 me = fv.m64[element];
-    V3 P{o.x + d.x * tnear, o.y + d.y * tnear, o.z + d.z * tnear};
-    V3 N{P.x - se.cx, P.y - se.cy, P.z - se.cz};
-    normalize_js(N);
-    if (d.x * N.x + d.y * N.y + d.z * N.z > 0) { N.x = -N.x; N.y = -N.y; N.z = -N.z; }
-    if (hit) { hit->P = P; hit->N = N; }
-
-    // shadow-ray origin (RayTracer.js:77, recomputed per j there; same value)
-    const V3 so{P.x + N.x * PTR_BIAS, P.y + N.y * PTR_BIAS, P.z + N.z * PTR_BIAS};
-
-    // every emissive element, scene order (RayTracer.js:61-91)
-    V3 acc{0, 0, 0};
-    const int nl = fv.h->n_lights;
-    for (int k = 0; k < nl; k++) {
-        const int i = fv.lights[k];
-        const SphereG64 li = fv.g64[i];
-        const SphereM64 lm = fv.m64[i];
-        count<STATS>(stats, ST_SHADOW);
-        V3 L{li.cx - P.x, li.cy - P.y, li.cz - P.z};
-        normalize_js(L);
-        double tr = 1.0;
-        for (int j = 0; j < n; j++) {
-            if (j == i) continue;
-            const SphereG64 s = fv.g64[j];
-            double lx = s.cx - so.x, ly = s.cy - so.y, lz = s.cz - so.z;
-            double tca = lx * L.x + ly * L.y + lz * L.z;
-            if (tca < 0) { count<STATS>(stats, ST_EXIT_TCA); continue; }
-            double d2 = (lx * lx + ly * ly + lz * lz) - tca * tca;
-            if (d2 > s.r2) { count<STATS>(stats, ST_EXIT_D2); continue; }
-            count<STATS>(stats, ST_EXIT_HIT);
-            tr = 0.0;                                  // any hit blocks; distance ignored (F7)
-            break;
-        }
-        double ratio = js_max0(N.x * L.x + N.y * L.y + N.z * L.z);
-        acc.x += (me.sr * tr) * (lm.er * ratio);       // RayTracer.js:89
-        acc.y += (me.sg * tr) * (lm.eg * ratio);
-        acc.z += (me.sb * tr) * (lm.eb * ratio);
-    }
-    acc.x += me.er; acc.y += me.eg; acc.z += me.eb;    // RayTracer.js:93
-    return acc;
+// RayTracer.trace for a ray whose nearest element the float32 kernel is certain of: that element's
+// Sphere.intersect alone gives tnear (same operations, so the same bits as the full search).
+__device__ V3 reshade_exact(const FrameView& fv, V3 o, V3 d, int element, uint32_t codes)
+{
+    const SphereG64 s = fv.g64[element];
+    double lx = s.cx - o.x, ly = s.cy - o.y, lz = s.cz - o.z;
+    double tca = lx * d.x + ly * d.y + lz * d.z;
+    double d2 = (lx * lx + ly * ly + lz * lz) - tca * tca;
+    double thc = __builtin_sqrt(s.r2 - d2);
+    double t0 = tca - thc, t1 = tca + thc;
+    if (t0 < 0) t0 = t1;
+    return shade_exact<false, true>(fv, o, d, element, t0, codes, nullptr, nullptr);
 }
 
 // camera ray for pixel (x, y) of the full image (RayTracer.js:171-174)
@@ -183,22 +212,27 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_exact_kernel(RenderArgs a)
     }
 }
 
-// hybrid mode, second kernel: re-trace the pixels the float32 kernel was not sure about.
-// One workgroup per sub-queue; the fill counts are read from device memory, so the host never
-// synchronises between the two kernels.
+// hybrid mode, second kernel: the pixels the float32 kernel was not sure about.
+// One workgroup per (sub-queue, kind); the fill counts are read from device memory, so the host never
+// synchronises between the two kernels.  kind 0 (blockIdx.y == 0): re-trace the pixel from scratch;
+// kind 1: the nearest element is certain and so are some of the shadow verdicts (qinfo), only the
+// shading is redone in float64 (entries stored from the back of the sub-queue).
 __global__ void __launch_bounds__(PTR_BLOCK) retrace_exact_kernel(RenderArgs a)
 {
-    // The grid always has PTR_MAX_QUEUES workgroups: every counter of the OTHER set is zeroed for the
+    // The grid always has PTR_MAX_QUEUES x 2 workgroups: every counter of the OTHER set is zeroed for the
     // next call (which may use more sub-queues than this one); workgroups past n_queues do only that.
-    const uint32_t sub = blockIdx.x;
-    if (threadIdx.x == 0) a.counter_next[sub * PTR_COUNTER_STRIDE] = 0u;
+    const uint32_t sub = blockIdx.x, kind = blockIdx.y;
+    if (threadIdx.x == 0 && blockIdx.z == 0) a.counter_next[sub * PTR_COUNTER_STRIDE + kind] = 0u;
     if (sub >= a.n_queues) return;
-    const uint32_t fill = a.counter[sub * PTR_COUNTER_STRIDE];
+    const uint32_t fill = a.counter[sub * PTR_COUNTER_STRIDE + kind];
     const uint32_t count = fill < a.queue_capacity ? fill : a.queue_capacity;
     const uint32_t* queue = a.queue + (uint64_t)sub * a.queue_capacity;
+    const uint32_t* qinfo = a.qinfo + 2 * (uint64_t)sub * a.queue_capacity;
     const uint64_t frame_px = (uint64_t)a.width * (uint64_t)a.scan_height;
-    for (uint32_t q = threadIdx.x; q < count; q += blockDim.x) {
-        const uint64_t gid = queue[q];
+    // gridDim.z workgroups share a sub-queue (many spheres: an entry is long, spread them wide)
+    for (uint32_t q = blockIdx.z * blockDim.x + threadIdx.x; q < count; q += blockDim.x * gridDim.z) {
+        const uint32_t slot = kind ? a.queue_capacity - 1u - q : q;
+        const uint64_t gid = queue[slot];
         if (gid >= frame_px * (uint64_t)a.n_frames) continue;      // never trust a queue word blindly
         const int frame = (int)(gid / frame_px);
         const uint32_t pix = (uint32_t)(gid - (uint64_t)frame * frame_px);
@@ -207,7 +241,14 @@ __global__ void __launch_bounds__(PTR_BLOCK) retrace_exact_kernel(RenderArgs a)
         const FrameView fv = frame_view(block);
         V3 o{a.cam.org[0], a.cam.org[1], a.cam.org[2]};
         V3 d = primary_dir_exact(a.cam, x, global_y(a, row));
-        V3 c = trace_exact<false>(fv, o, d, nullptr, nullptr);
+        V3 c;
+        if (kind) {
+            const uint32_t element = qinfo[2 * slot], codes = qinfo[2 * slot + 1];
+            if (element >= (uint32_t)fv.h->n) continue;
+            c = reshade_exact(fv, o, d, (int)element, codes);
+        } else {
+            c = trace_exact<false>(fv, o, d, nullptr, nullptr);
+        }
         const long long idx = store_index(a, x, row);
         if (idx >= 0) a.out8[frame * a.out_frame_stride + idx] = pack_js(c.x, c.y, c.z);
         if (a.out32f) {
@@ -215,7 +256,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) retrace_exact_kernel(RenderArgs a)
             p[0] = (float)c.x; p[1] = (float)c.y; p[2] = (float)c.z; p[3] = 1.0f;
         }
     }
-    if (threadIdx.x == 0 && a.stats) atomicAdd(&a.stats[ST_RETRACED], (unsigned long long)count);
+    if (threadIdx.x == 0 && blockIdx.z == 0 && a.stats) atomicAdd(&a.stats[kind ? ST_RESHADED : ST_RETRACED], (unsigned long long)count);
 }
 
 __global__ void __launch_bounds__(PTR_BLOCK) trace_batch_exact_kernel(TraceArgs a)
@@ -243,9 +284,9 @@ hipError_t launch_render_exact(const RenderArgs& a, int n_frames, bool stats, hi
     return hipGetLastError();
 }
 
-hipError_t launch_retrace_exact(const RenderArgs& a, hipStream_t s)
+hipError_t launch_retrace_exact(const RenderArgs& a, int split, hipStream_t s)
 {
-    hipLaunchKernelGGL(retrace_exact_kernel, dim3(PTR_MAX_QUEUES), dim3(PTR_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(retrace_exact_kernel, dim3(PTR_MAX_QUEUES, 2, split), dim3(PTR_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 

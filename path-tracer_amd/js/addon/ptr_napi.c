@@ -16,7 +16,7 @@
  *   traceBatch(h, Float64Array origins | null, Float64Array dirs)
  *        -> { rgb: Float64Array, element: Int32Array, hit: Float64Array, normal: Float64Array }
  *                                                                            ptr_trace_batch_f64
- *   stats(h) -> { primary, hits, shadowRays, exitTca, exitD2, exitHit, retraced }   ptr_get_stats
+ *   stats(h) -> { primary, hits, shadowRays, exitTca, exitD2, exitHit, retraced, reshaded }   ptr_get_stats
  */
 #include <node_api.h>
 #include <stdint.h>
@@ -383,9 +383,9 @@ static napi_value js_stats(napi_env env, napi_callback_info info)
     if (rc != PTR_OK) return throw_ptr(env, ctx, rc);
     napi_value out, v;
     NAPI_TRY(env, napi_create_object(env, &out));
-    const char *names[] = {"primary", "hits", "shadowRays", "exitTca", "exitD2", "exitHit", "retraced"};
-    const uint64_t vals[] = {st.primary, st.hits, st.shadow_rays, st.exit_tca, st.exit_d2, st.exit_hit, st.retraced};
-    for (int k = 0; k < 7; k++) {
+    const char *names[] = {"primary", "hits", "shadowRays", "exitTca", "exitD2", "exitHit", "retraced", "reshaded"};
+    const uint64_t vals[] = {st.primary, st.hits, st.shadow_rays, st.exit_tca, st.exit_d2, st.exit_hit, st.retraced, st.reshaded};
+    for (int k = 0; k < 8; k++) {
         NAPI_TRY(env, napi_create_double(env, (double)vals[k], &v));
         NAPI_TRY(env, napi_set_named_property(env, out, names[k], v));
     }

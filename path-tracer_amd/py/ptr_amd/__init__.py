@@ -18,6 +18,7 @@ MODE_F32_ONLY = 0x0004
 FLAG_STATS = 0x0008
 FLAG_TIMING = 0x0010
 DEBUG_REASONS = 0x8000
+DEBUG_FORCE_MANY = 0x4000
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NO_SCENE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 
@@ -66,7 +67,7 @@ class StripPart:
 
 class Stats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in
-                ("primary", "hits", "shadow_rays", "exit_tca", "exit_d2", "exit_hit", "retraced")]
+                ("primary", "hits", "shadow_rays", "exit_tca", "exit_d2", "exit_hit", "retraced", "reshaded")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
