@@ -190,6 +190,32 @@ def main():
     main_ms = float(np.mean([k[0] for k in kms]))
     retrace_ms = float(np.mean([k[1] for k in kms]))
 
+    # ---- BASELINE.json configs[1] as written ("depth 5"): an EXTENSION (the reference has no bounce loop,
+    # SURVEY.md F1), reported beside the headline, same scene / size / batch, float32 extension kernel
+    depth5 = None
+    if world == 1:
+        p5s = rdr.params(WIDTH, HEIGHT, flags=ptr_amd.FLAG_STATS, max_depth=5)
+        rdr.render_device(p5s, 0, 1, one.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        st5 = rdr.stats()
+        rays5 = st5["primary"] + st5["secondary"] + st5["shadow_rays"]
+        p5 = rdr.params(WIDTH, HEIGHT, flags=ptr_amd.MODE_F32_ONLY, max_depth=5)
+        for _ in range(2):
+            rdr.render_device(p5, 0, frames_total, local.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        n5 = max(3, min(args.steps, 10))
+        t5 = time.perf_counter()
+        for _ in range(n5):
+            rdr.render_device(p5, 0, frames_total, local.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        dt5 = time.perf_counter() - t5
+        depth5 = {"workload": f"BASELINE.json configs[1]: example1 {WIDTH}x{HEIGHT}, depth 5, 1 spp, {frames_total} frames per step",
+                  "value": round(rays5 * frames_total * n5 / dt5 / 1e6, 1), "unit": "Mrays/s",
+                  "ms_per_step": round(dt5 / n5 * 1e3, 4), "rays_per_frame": rays5,
+                  "camera_rays": st5["primary"], "secondary_rays": st5["secondary"], "shadow_rays": st5["shadow_rays"],
+                  "dtype": "f32", "note": "extension mode, specification in include/ptr.h; not reference behaviour "
+                                          "(parity vs the float64 specification: tests/test_gpu_ext.py)"}
+
     if args.check and rank == 0:
         whole = torch.empty((HEIGHT, WIDTH), dtype=torch.int32, device="cuda")
         rdr.render_device(rdr.params(WIDTH, HEIGHT, flags=0), 0, 1, whole.data_ptr(), stream=stream)
@@ -226,6 +252,8 @@ def main():
                          "note": "FP32 vector-ALU bound (SURVEY.md 8d): no dense contraction, 4 B/pixel of HBM "
                                  "traffic; achieved = algorithmic FLOPs of the reference's control flow"},
         }
+        if depth5 is not None:
+            out["extension_depth5"] = depth5
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(soa, bg)
         print(json.dumps(out), flush=True)

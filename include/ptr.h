@@ -82,7 +82,7 @@ typedef struct ptr_ctx ptr_ctx;
  *   pixel is the mean of the samples (summed in sample order, one divide), then packed as ever.
  * With max_depth 0 and spp 1 a call has the reference semantics.  In the extension modes PTR_MODE_EXACT_F64 renders that specification bit
  * for bit, any other mode renders it in float32 (tolerance: see tests/test_gpu_ext.py);
- * PTR_QUIRK_ROW_SHIFT and PTR_FLAG_STATS are rejected.                                       */
+ * PTR_QUIRK_ROW_SHIFT is rejected.                                       */
 #define PTR_MAX_DEPTH_LIMIT 16
 #define PTR_MAX_SPP         65536
 typedef struct ptr_params {
@@ -121,6 +121,7 @@ typedef struct ptr_stats {
     uint64_t retraced;      /* hybrid mode: pixels re-traced in float64 (last call, always set) */
     uint64_t reshaded;      /* hybrid mode: pixels whose nearest element was certain and only the
                                shading was redone in float64 (last call, always set)            */
+    uint64_t secondary;     /* extension modes: reflection + refraction rays (primary counts camera rays) */
 } ptr_stats;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */

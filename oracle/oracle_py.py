@@ -62,6 +62,9 @@ def lib():
         L.orc_render_ext.argtypes = [dp, C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_uint32, C.POINTER(C.c_uint32), dp, C.c_int]
         L.orc_render_ext.restype = None
+        L.orc_count_ext.argtypes = [dp, C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_uint32, C.POINTER(Counters), C.POINTER(C.c_uint64)]
+        L.orc_count_ext.restype = None
         L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.orc_philox4x32_10.restype = None
         L.orc_pack.argtypes = [dp]
@@ -191,6 +194,16 @@ def render_ext(soa, bg, width, height, start_y=0, scan_height=None, max_depth=0,
     lib().orc_render_ext(_dp(soa), soa.shape[1], _dp(bg), width, height, start_y, scan_height, max_depth, spp,
                          seed, out.ctypes.data_as(C.POINTER(C.c_uint32)), _dp(rgb) if want_rgb64 else None, threads)
     return (out, rgb) if want_rgb64 else out
+
+
+def count_ext(soa, bg, width, height, max_depth=0, spp=1, seed=0):
+    soa = np.ascontiguousarray(soa, dtype=np.float64)
+    bg = np.ascontiguousarray(bg, dtype=np.float64)
+    cnt = Counters(); sec = C.c_uint64(0)
+    lib().orc_count_ext(_dp(soa), soa.shape[1], _dp(bg), width, height, 0, height, max_depth, spp, seed,
+                        C.byref(cnt), C.byref(sec))
+    d = cnt.as_dict(); d["secondary"] = int(sec.value)
+    return d
 
 
 def trace_ext(soa, bg, o, d, max_depth):

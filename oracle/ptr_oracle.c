@@ -284,14 +284,14 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 typedef struct { double o[3], d[3], w[3]; int depth; } ext_ray;
 
 /* nearest hit + hit frame shared by every node of the expansion (same arithmetic as orc_trace) */
-static int ext_nearest(const double *soa, int n, const double o[3], const double d[3], double *tnear_out)
+static int ext_nearest(const double *soa, int n, const double o[3], const double d[3], double *tnear_out, orc_counters *cnt)
 {
     const double *cx = PL(0), *cy = PL(1), *cz = PL(2), *rad = PL(3);
     double tnear = ORC_INFINITY;
     int element = -1;
     for (int i = 0; i < n; i++) {
         double t0 = ORC_INFINITY, t1 = ORC_INFINITY;
-        if (intersect_r2(o, d, cx[i], cy[i], cz[i], rad[i] * rad[i], &t0, &t1, 0)) {
+        if (intersect_r2(o, d, cx[i], cy[i], cz[i], rad[i] * rad[i], &t0, &t1, cnt)) {
             if (t0 < 0) t0 = t1;
             if (t0 < tnear) { tnear = t0; element = i; }
         }
@@ -300,8 +300,19 @@ static int ext_nearest(const double *soa, int n, const double o[3], const double
     return element;
 }
 
+static void trace_ext_counted(const double *soa, int n, const double bg[3],
+                              const double o[3], const double d[3], int max_depth, double rgb[3],
+                              orc_counters *cnt, uint64_t *secondary);
+
 void orc_trace_ext(const double *soa, int n, const double bg[3],
                    const double o[3], const double d[3], int max_depth, double rgb[3])
+{
+    trace_ext_counted(soa, n, bg, o, d, max_depth, rgb, 0, 0);
+}
+
+static void trace_ext_counted(const double *soa, int n, const double bg[3],
+                              const double o[3], const double d[3], int max_depth, double rgb[3],
+                              orc_counters *cnt, uint64_t *secondary)
 {
     const double *cx = PL(0), *cy = PL(1), *cz = PL(2), *rad = PL(3);
     const double *sr = PL(4), *sg = PL(5), *sb = PL(6), *refl = PL(7), *transp = PL(8);
@@ -316,11 +327,12 @@ void orc_trace_ext(const double *soa, int n, const double bg[3],
     while (top > 0) {
         const ext_ray r = stack[--top];
         double tnear;
-        const int e = ext_nearest(soa, n, r.o, r.d, &tnear);
+        const int e = ext_nearest(soa, n, r.o, r.d, &tnear, cnt);
         if (e < 0) {
             acc[0] += r.w[0] * bg[0]; acc[1] += r.w[1] * bg[1]; acc[2] += r.w[2] * bg[2];
             continue;
         }
+        if (cnt) cnt->hits++;
         acc[0] += r.w[0] * er[e]; acc[1] += r.w[1] * eg[e]; acc[2] += r.w[2] * eb[e];
         double P[3] = { r.o[0] + r.d[0] * tnear, r.o[1] + r.d[1] * tnear, r.o[2] + r.d[2] * tnear };
         double N[3] = { P[0] - cx[e], P[1] - cy[e], P[2] - cz[e] };
@@ -339,6 +351,7 @@ void orc_trace_ext(const double *soa, int n, const double bg[3],
                 const double k = 1 - eta * eta * (1 - cosi * cosi);
                 if (k >= 0) {
                     ext_ray *c = &stack[top++];
+                    if (secondary) (*secondary)++;
                     const double g = eta * cosi - sqrt(k);
                     const double wt = (1 - fresnel) * transp[e];
                     for (int a = 0; a < 3; a++) {
@@ -351,6 +364,7 @@ void orc_trace_ext(const double *soa, int n, const double bg[3],
                 }
             }
             ext_ray *c = &stack[top++];
+            if (secondary) (*secondary)++;
             const double two = 2 * dn;
             for (int a = 0; a < 3; a++) {
                 c->o[a] = P[a] + N[a] * ORC_BIAS;
@@ -367,11 +381,12 @@ void orc_trace_ext(const double *soa, int n, const double bg[3],
                     double tr = 1.0;
                     double L[3] = { cx[i] - P[0], cy[i] - P[1], cz[i] - P[2] };
                     v_normalize(L);
+                    if (cnt) cnt->shadow_rays++;
                     for (int j = 0; j < n; j++) {
                         if (i != j) {
                             double so[3] = { P[0] + N[0] * ORC_BIAS, P[1] + N[1] * ORC_BIAS, P[2] + N[2] * ORC_BIAS };
                             double t0, t1;
-                            if (intersect_r2(so, L, cx[j], cy[j], cz[j], rad[j] * rad[j], &t0, &t1, 0)) { tr = 0.0; break; }
+                            if (intersect_r2(so, L, cx[j], cy[j], cz[j], rad[j] * rad[j], &t0, &t1, cnt)) { tr = 0.0; break; }
                         }
                     }
                     double ratio = js_max0(N[0] * L[0] + N[1] * L[1] + N[2] * L[2]);
@@ -389,6 +404,7 @@ void orc_trace_ext(const double *soa, int n, const double bg[3],
 typedef struct {
     const double *soa; int n; const double *bg; int width, height, start_y, scan_height;
     int max_depth, spp; uint32_t seed; uint32_t *out8; double *out64; int first, step;
+    orc_counters *cnt; uint64_t *secondary;          /* single-threaded callers only */
 } ext_job;
 
 static void *ext_main(void *p)
@@ -413,7 +429,8 @@ static void *ext_main(void *p)
                 double dir[3] = { (2 * (px * invW) - 1) * angle * aspect, (1 - 2 * (py * invH)) * angle, -1 };
                 v_normalize(dir);
                 double c[3];
-                orc_trace_ext(j->soa, j->n, j->bg, origin, dir, j->max_depth, c);
+                if (j->cnt) j->cnt->primary++;
+                trace_ext_counted(j->soa, j->n, j->bg, origin, dir, j->max_depth, c, j->cnt, j->secondary);
                 sum[0] += c[0]; sum[1] += c[1]; sum[2] += c[2];
             }
             if (j->spp > 1) { sum[0] /= j->spp; sum[1] /= j->spp; sum[2] /= j->spp; }
@@ -434,10 +451,20 @@ void orc_render_ext(const double *soa, int n, const double bg[3],
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
     ext_job *jobs = (ext_job *)malloc(sizeof(ext_job) * (size_t)nthreads);
     for (int t = 0; t < nthreads; t++) {
-        ext_job j = { soa, n, bg, width, height, start_y, scan_height, max_depth, spp, seed, out_rgba8, out_rgb64, t, nthreads };
+        ext_job j = { soa, n, bg, width, height, start_y, scan_height, max_depth, spp, seed, out_rgba8, out_rgb64, t, nthreads, 0, 0 };
         jobs[t] = j;
         pthread_create(&th[t], 0, ext_main, &jobs[t]);
     }
     for (int t = 0; t < nthreads; t++) pthread_join(th[t], 0);
     free(th); free(jobs);
+}
+
+void orc_count_ext(const double *soa, int n, const double bg[3],
+                   int width, int height, int start_y, int scan_height,
+                   int max_depth, int spp, uint32_t seed, orc_counters *cnt, uint64_t *secondary)
+{
+    memset(cnt, 0, sizeof *cnt);
+    *secondary = 0;
+    ext_job j = { soa, n, bg, width, height, start_y, scan_height, max_depth, spp < 1 ? 1 : spp, seed, 0, 0, 0, 1, cnt, secondary };
+    ext_main(&j);
 }

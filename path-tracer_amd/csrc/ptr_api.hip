@@ -280,8 +280,6 @@ int check_params(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frames)
         if (p->flags & PTR_QUIRK_ROW_SHIFT)
             return fail(c, PTR_ERR_INVALID, "PTR_QUIRK_ROW_SHIFT applies to the reference semantics only "
                                             "(max_depth 0, spp 1); got max_depth=%d spp=%d", p->max_depth, p->spp);
-        if (p->flags & PTR_FLAG_STATS)
-            return fail(c, PTR_ERR_UNSUPPORTED, "PTR_FLAG_STATS counts the reference path only (max_depth 0, spp 1)");
     }
     if ((p->flags & PTR_MODE_EXACT_F64) && (p->flags & PTR_MODE_F32_ONLY))
         return fail(c, PTR_ERR_INVALID, "PTR_MODE_EXACT_F64 and PTR_MODE_F32_ONLY are exclusive");
@@ -358,7 +356,7 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
     if (p->max_depth != 0 || p->spp != 1) {
         // extension modes: float64 = the specification bit for bit; anything else = float32 throughput form
         a.max_depth = p->max_depth; a.spp = p->spp; a.seed = p->seed;
-        HIP_TRY(c, launch_render_ext(a, n_frames, exact, s));
+        HIP_TRY(c, launch_render_ext(a, n_frames, exact, stats, s));
         if (timing) { HIP_TRY(c, hipEventRecord(c->ev[1], s)); c->timed_kernels = 1; }
         return PTR_OK;
     }
@@ -713,10 +711,10 @@ int ptr_get_stats(ptr_ctx* c, ptr_stats* out)
     if (!c->words.ptr) return PTR_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    unsigned long long w[8];
+    unsigned long long w[9];
     HIP_TRY(c, hipMemcpy(w, static_cast<unsigned char*>(c->words.ptr) + WORDS_STATS, sizeof w, hipMemcpyDeviceToHost));
     out->primary = w[0]; out->hits = w[1]; out->shadow_rays = w[2];
-    out->exit_tca = w[3]; out->exit_d2 = w[4]; out->exit_hit = w[5]; out->retraced = w[6]; out->reshaded = w[7];
+    out->exit_tca = w[3]; out->exit_d2 = w[4]; out->exit_hit = w[5]; out->retraced = w[6]; out->reshaded = w[7]; out->secondary = w[8];
     return PTR_OK;
 }
 

@@ -53,15 +53,21 @@ template <> struct SceneT<float> {
     __device__ V<float> bg() const { return V<float>{fv.h->bg32[0], fv.h->bg32[1], fv.h->bg32[2]}; }
 };
 
+// per-lane work counters (PTR_FLAG_STATS), same meaning as ptr_stats in include/ptr.h
+enum { XT_CAMERA = 0, XT_HITS, XT_SHADOW, XT_EXIT_TCA, XT_EXIT_D2, XT_EXIT_HIT, XT_SECONDARY, XT_N };
+struct ExtCounts { unsigned c[XT_N] = {0, 0, 0, 0, 0, 0, 0}; };
+template <bool STATS> __device__ __forceinline__ void xcount(ExtCounts* k, int which) { if constexpr (STATS) k->c[which]++; }
+
 // Sphere.intersect (Sphere.js:15-33); any_hit skips the unused sqrt of the shadow test
-template <typename T>
-__device__ __forceinline__ bool intersect_t(const V<T>& o, const V<T>& d, const V<T>& c, T r2, T& t0, T& t1, bool any_hit)
+template <typename T, bool STATS>
+__device__ __forceinline__ bool intersect_t(const V<T>& o, const V<T>& d, const V<T>& c, T r2, T& t0, T& t1, bool any_hit, ExtCounts* k)
 {
     const T lx = c.x - o.x, ly = c.y - o.y, lz = c.z - o.z;
     const T tca = lx * d.x + ly * d.y + lz * d.z;
-    if (tca < 0) return false;
+    if (tca < 0) { xcount<STATS>(k, XT_EXIT_TCA); return false; }
     const T d2 = (lx * lx + ly * ly + lz * lz) - tca * tca;
-    if (d2 > r2) return false;
+    if (d2 > r2) { xcount<STATS>(k, XT_EXIT_D2); return false; }
+    xcount<STATS>(k, XT_EXIT_HIT);
     if (!any_hit) {
         const T thc = tsqrt<T>(r2 - d2);
         t0 = tca - thc; t1 = tca + thc;
@@ -72,8 +78,8 @@ __device__ __forceinline__ bool intersect_t(const V<T>& o, const V<T>& d, const 
 template <typename T> struct ExtRay { V<T> o, d, w; int depth; };
 
 // weighted depth-first expansion (include/ptr.h, "extension modes")
-template <typename T>
-__device__ V<T> trace_ext(const SceneT<T>& sc, V<T> o0, V<T> d0, int max_depth)
+template <typename T, bool STATS>
+__device__ V<T> trace_ext(const SceneT<T>& sc, V<T> o0, V<T> d0, int max_depth, ExtCounts* k)
 {
     const int n = sc.fv.h->n, nl = sc.fv.h->n_lights;
     ExtRay<T> stack[PTR_EXT_MAX_DEPTH + 2];
@@ -87,7 +93,7 @@ __device__ V<T> trace_ext(const SceneT<T>& sc, V<T> o0, V<T> d0, int max_depth)
         int e = -1;
         for (int i = 0; i < n; i++) {
             T t0 = T(PTR_INFINITY), t1 = T(PTR_INFINITY);
-            if (intersect_t<T>(r.o, r.d, sc.center(i), sc.r2(i), t0, t1, false)) {
+            if (intersect_t<T, STATS>(r.o, r.d, sc.center(i), sc.r2(i), t0, t1, false, k)) {
                 if (t0 < 0) t0 = t1;
                 if (t0 < tnear) { tnear = t0; e = i; }
             }
@@ -96,6 +102,7 @@ __device__ V<T> trace_ext(const SceneT<T>& sc, V<T> o0, V<T> d0, int max_depth)
             acc.x += r.w.x * bg.x; acc.y += r.w.y * bg.y; acc.z += r.w.z * bg.z;
             continue;
         }
+        xcount<STATS>(k, XT_HITS);
         const V<T> em = sc.em(e), col = sc.sc(e), C = sc.center(e);
         acc.x += r.w.x * em.x; acc.y += r.w.y * em.y; acc.z += r.w.z * em.z;
         const V<T> P{r.o.x + r.d.x * tnear, r.o.y + r.d.y * tnear, r.o.z + r.d.z * tnear};
@@ -113,10 +120,11 @@ __device__ V<T> trace_ext(const SceneT<T>& sc, V<T> o0, V<T> d0, int max_depth)
             if (transp > 0) {
                 const T eta = inside ? T(1.1) : T(1) / T(1.1);
                 const T cosi = -dn;
-                const T k = 1 - eta * eta * (1 - cosi * cosi);
-                if (k >= 0) {
+                const T kk2 = 1 - eta * eta * (1 - cosi * cosi);
+                if (kk2 >= 0) {
                     ExtRay<T>& c = stack[top++];
-                    const T g = eta * cosi - tsqrt<T>(k);
+                    xcount<STATS>(k, XT_SECONDARY);
+                    const T g = eta * cosi - tsqrt<T>(kk2);
                     const T wt = (1 - fresnel) * transp;
                     c.o = V<T>{P.x - N.x * T(PTR_BIAS), P.y - N.y * T(PTR_BIAS), P.z - N.z * T(PTR_BIAS)};
                     c.d = V<T>{r.d.x * eta + N.x * g, r.d.y * eta + N.y * g, r.d.z * eta + N.z * g};
@@ -126,6 +134,7 @@ __device__ V<T> trace_ext(const SceneT<T>& sc, V<T> o0, V<T> d0, int max_depth)
                 }
             }
             ExtRay<T>& c = stack[top++];
+            xcount<STATS>(k, XT_SECONDARY);
             const T two = 2 * dn;
             c.o = V<T>{P.x + N.x * T(PTR_BIAS), P.y + N.y * T(PTR_BIAS), P.z + N.z * T(PTR_BIAS)};
             c.d = V<T>{r.d.x - N.x * two, r.d.y - N.y * two, r.d.z - N.z * two};
@@ -141,11 +150,12 @@ __device__ V<T> trace_ext(const SceneT<T>& sc, V<T> o0, V<T> d0, int max_depth)
                 const V<T> Ci = sc.center(i), ei = sc.em(i);
                 V<T> L{Ci.x - P.x, Ci.y - P.y, Ci.z - P.z};
                 normalize_v(L);
+                xcount<STATS>(k, XT_SHADOW);
                 T tr = 1;
                 for (int j = 0; j < n; j++) {
                     if (j == i) continue;
                     T t0, t1;
-                    if (intersect_t<T>(so, L, sc.center(j), sc.r2(j), t0, t1, true)) { tr = 0; break; }
+                    if (intersect_t<T, STATS>(so, L, sc.center(j), sc.r2(j), t0, t1, true, k)) { tr = 0; break; }
                 }
                 T ratio = N.x * L.x + N.y * L.y + N.z * L.z;
                 ratio = (ratio != ratio) ? ratio : (ratio > 0 ? ratio : T(0));       // Math.max(0, .)
@@ -174,13 +184,9 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     r0 = c0; r1 = c1;
 }
 
-template <typename T>
-__global__ void __launch_bounds__(PTR_BLOCK) render_ext_kernel(RenderArgs a)
+template <typename T, bool STATS>
+__device__ __forceinline__ void render_ext_pixel(const RenderArgs& a, int x, int row, ExtCounts* k)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = blockIdx.x * PTR_TILE_W + wave * 8 + (lane & 7);
-    const int row = blockIdx.y * PTR_TILE_H + (lane >> 3);
-    if (x >= a.width || row >= a.scan_height) return;
     const int frame = blockIdx.z;
     const int y = global_y(a, row);
     SceneT<T> sc;
@@ -209,7 +215,8 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_ext_kernel(RenderArgs a)
             d = V<T>{xx, yy, T(-1)};
         }
         normalize_v(d);
-        const V<T> c = trace_ext<T>(sc, origin, d, a.max_depth);
+        xcount<STATS>(k, XT_CAMERA);
+        const V<T> c = trace_ext<T, STATS>(sc, origin, d, a.max_depth, k);
         sum.x += c.x; sum.y += c.y; sum.z += c.z;
     }
     if (a.spp > 1) { const T k = T(a.spp); sum.x /= k; sum.y /= k; sum.z /= k; }
@@ -221,11 +228,34 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_ext_kernel(RenderArgs a)
     }
 }
 
-hipError_t launch_render_ext(const RenderArgs& a, int n_frames, bool f64, hipStream_t s)
+template <typename T, bool STATS>
+__global__ void __launch_bounds__(PTR_BLOCK) render_ext_kernel(RenderArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * PTR_TILE_W + wave * 8 + (lane & 7);
+    const int row = blockIdx.y * PTR_TILE_H + (lane >> 3);
+    ExtCounts cnt;
+    if (x < a.width && row < a.scan_height) render_ext_pixel<T, STATS>(a, x, row, &cnt);
+    if constexpr (STATS) {
+        // stats words: primary hits shadow exit_tca exit_d2 exit_hit | retraced reshaded | secondary
+        __shared__ unsigned block_cnt[XT_N];
+        if (threadIdx.x < XT_N) block_cnt[threadIdx.x] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < XT_N; i++)
+            if (cnt.c[i]) atomicAdd(&block_cnt[i], cnt.c[i]);
+        __syncthreads();
+        if (threadIdx.x < XT_N && block_cnt[threadIdx.x])
+            atomicAdd(&a.stats[threadIdx.x == XT_SECONDARY ? 8 : threadIdx.x], (unsigned long long)block_cnt[threadIdx.x]);
+    }
+}
+
+hipError_t launch_render_ext(const RenderArgs& a, int n_frames, bool f64, bool stats, hipStream_t s)
 {
     dim3 grid((a.width + PTR_TILE_W - 1) / PTR_TILE_W, (a.scan_height + PTR_TILE_H - 1) / PTR_TILE_H, n_frames);
-    if (f64) hipLaunchKernelGGL(render_ext_kernel<double>, grid, dim3(PTR_BLOCK), 0, s, a);
-    else     hipLaunchKernelGGL(render_ext_kernel<float>, grid, dim3(PTR_BLOCK), 0, s, a);
+    if (stats) hipLaunchKernelGGL((render_ext_kernel<double, true>), grid, dim3(PTR_BLOCK), 0, s, a);
+    else if (f64) hipLaunchKernelGGL((render_ext_kernel<double, false>), grid, dim3(PTR_BLOCK), 0, s, a);
+    else     hipLaunchKernelGGL((render_ext_kernel<float, false>), grid, dim3(PTR_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 

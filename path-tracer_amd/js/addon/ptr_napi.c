@@ -383,9 +383,9 @@ static napi_value js_stats(napi_env env, napi_callback_info info)
     if (rc != PTR_OK) return throw_ptr(env, ctx, rc);
     napi_value out, v;
     NAPI_TRY(env, napi_create_object(env, &out));
-    const char *names[] = {"primary", "hits", "shadowRays", "exitTca", "exitD2", "exitHit", "retraced", "reshaded"};
-    const uint64_t vals[] = {st.primary, st.hits, st.shadow_rays, st.exit_tca, st.exit_d2, st.exit_hit, st.retraced, st.reshaded};
-    for (int k = 0; k < 8; k++) {
+    const char *names[] = {"primary", "hits", "shadowRays", "exitTca", "exitD2", "exitHit", "retraced", "reshaded", "secondary"};
+    const uint64_t vals[] = {st.primary, st.hits, st.shadow_rays, st.exit_tca, st.exit_d2, st.exit_hit, st.retraced, st.reshaded, st.secondary};
+    for (int k = 0; k < 9; k++) {
         NAPI_TRY(env, napi_create_double(env, (double)vals[k], &v));
         NAPI_TRY(env, napi_set_named_property(env, out, names[k], v));
     }

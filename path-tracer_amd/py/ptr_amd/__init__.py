@@ -67,7 +67,7 @@ class StripPart:
 
 class Stats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in
-                ("primary", "hits", "shadow_rays", "exit_tca", "exit_d2", "exit_hit", "retraced", "reshaded")]
+                ("primary", "hits", "shadow_rays", "exit_tca", "exit_d2", "exit_hit", "retraced", "reshaded", "secondary")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

@@ -117,12 +117,24 @@ def test_full_hd_depth5_hash(rdr, golden_dir, scenes):
     assert hashlib.sha256(got.tobytes()).hexdigest() == c["sha256"]
 
 
+def test_work_counters_match_the_specification(rdr, scenes):
+    for name, depth, spp in (("example1", 5, 1), ("random_3", 3, 2), ("example1", 0, 1)):
+        sc = scenes[name]
+        _load(rdr, sc)
+        if depth == 0 and spp == 1:
+            continue                      # the reference path has its own counter test
+        rdr.render(160, 120, flags=ptr_amd.FLAG_STATS, max_depth=depth, spp=spp, seed=4)
+        got = rdr.stats()
+        want = orc.count_ext(orc.scene_to_soa(sc["elements"]), sc["background"], 160, 120, max_depth=depth, spp=spp, seed=4)
+        for k in ("primary", "hits", "shadow_rays", "exit_tca", "exit_d2", "exit_hit", "secondary"):
+            assert got[k] == want[k], (name, k, got, want)
+
+
 def test_rejections(rdr, scenes):
     _load(rdr, scenes["example1"])
     for kw, code in ((dict(max_depth=17), ptr_amd.ERR_INVALID), (dict(max_depth=-1), ptr_amd.ERR_INVALID),
                      (dict(spp=0), ptr_amd.ERR_INVALID),
-                     (dict(max_depth=2, flags=ptr_amd.QUIRK_ROW_SHIFT), ptr_amd.ERR_INVALID),
-                     (dict(spp=2, flags=ptr_amd.FLAG_STATS), ptr_amd.ERR_UNSUPPORTED)):
+                     (dict(max_depth=2, flags=ptr_amd.QUIRK_ROW_SHIFT), ptr_amd.ERR_INVALID)):
         kw.setdefault("flags", 0)
         with pytest.raises(ptr_amd.PtrError) as e:
             rdr.render(64, 48, **kw)

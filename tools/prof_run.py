@@ -1,5 +1,5 @@
 """Small fixed workload for rocprofv3: N launches of the bench step (64 frames of the example
-scene at 1080p, hybrid mode).  Usage: python tools/prof_run.py [steps] [frames] [mode]"""
+scene at 1080p, hybrid mode).  Usage: python tools/prof_run.py [steps] [frames] [mode] [example1|many]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "path-tracer_amd", "py")]
@@ -10,8 +10,12 @@ from bench import example1_soa, WIDTH, HEIGHT
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-mode = {"hybrid": 0, "f32": ptr_amd.MODE_F32_ONLY, "exact": ptr_amd.MODE_EXACT_F64}[sys.argv[3] if len(sys.argv) > 3 else "hybrid"]
+mode = {"hybrid": 0, "f32": ptr_amd.MODE_F32_ONLY, "exact": ptr_amd.MODE_EXACT_F64,
+        "hybrid_many": ptr_amd.DEBUG_FORCE_MANY, "f32_many": ptr_amd.MODE_F32_ONLY | ptr_amd.DEBUG_FORCE_MANY}[sys.argv[3] if len(sys.argv) > 3 else "hybrid"]
 soa = example1_soa()
+if len(sys.argv) > 4 and sys.argv[4] == "many":
+    from ptr_amd import synthetic
+    soa = synthetic.many_spheres()
 r = ptr_amd.Renderer(0)
 r.set_scene(np.ascontiguousarray(np.broadcast_to(soa, (frames,) + soa.shape)))
 r.set_background([2.0, 2.0, 2.0])
