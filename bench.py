@@ -77,6 +77,27 @@ def cpu_baseline(soa, bg, seconds=12.0):
                       f"oracle/ptr_oracle.c (float64 C port of the reference) on {threads} pthreads"}
 
 
+def cpu_baseline_js(seconds=8.0):
+    """The JavaScript CPU port (oracle/js, the reference's style and speed class) under Node worker_threads,
+    one Worker per scanline band as the reference's RenderPlanner does (RT/src/RenderPlanner.js:75-76)."""
+    import shutil
+    import subprocess
+    node = shutil.which("node")
+    if not node:
+        return {"value": None, "note": "no node on this host"}
+    threads = max(1, min(16, os.cpu_count() or 1))
+    try:
+        res = subprocess.run([node, os.path.join(ROOT, "oracle", "js", "cpu_bench.mjs"), str(threads), str(seconds)],
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=seconds * 6 + 60, check=True)
+        r = json.loads(res.stdout.decode().strip().splitlines()[-1])
+    except Exception as e:                       # a baseline, not the product: report and go on
+        return {"value": None, "note": f"node run failed: {e}"}
+    return {"value": round(r["mrays_per_s"], 2), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{r['frames']} frames of the example scene at {WIDTH}x{HEIGHT} in {r['seconds']:.1f} s, "
+                      f"oracle/js/cpu_port.mjs (JavaScript port in the reference's object style) on {threads} "
+                      f"worker_threads, node {r['node']}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -256,6 +277,7 @@ def main():
             out["extension_depth5"] = depth5
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(soa, bg)
+            out["cpu_baseline_js"] = cpu_baseline_js()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
