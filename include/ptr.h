@@ -54,7 +54,7 @@ extern "C" {
  * 4 nearest-vs-second ordering, 8 far clip, 16 shadow band, 32 rounding band).               */
 #define PTR_DEBUG_REASONS     0x8000u
 /* Diagnostics/tests: use the many-sphere float32 kernel (sphere list staged through LDS, chosen by
- * itself above 128 spheres) whatever the sphere count.  Same results contract as the default.     */
+ * itself above 12 spheres) whatever the sphere count.  Same results contract as the default.     */
 #define PTR_DEBUG_FORCE_MANY  0x4000u
 
 typedef struct ptr_ctx ptr_ctx;

@@ -365,7 +365,7 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
         if (timing) { HIP_TRY(c, hipEventRecord(c->ev[1], s)); c->timed_kernels = 1; }
         return PTR_OK;
     }
-    const bool many = c->n_spheres > PTR_MANY_THRESHOLD || (p->flags & PTR_DEBUG_FORCE_MANY);
+    const bool many = c->n_spheres > PTR_FAST_MAX_SPHERES || (p->flags & PTR_DEBUG_FORCE_MANY);
     if (p->flags & PTR_MODE_F32_ONLY) {
         HIP_TRY(c, many ? launch_render_many(a, n_frames, false, s) : launch_render_fast(a, n_frames, false, s));
         if (timing) { HIP_TRY(c, hipEventRecord(c->ev[1], s)); c->timed_kernels = 1; }

@@ -17,7 +17,9 @@
 #define PTR_FAST_PPL 2            // pixels per lane in the float32 kernel (wave tile 8 x 16)
 #define PTR_MAX_QUEUES 1024       // sub-queues of the hybrid mode's re-trace queue
 #define PTR_MAX_PAIR_LIGHTS 64     // lights with a shadow pre-filter table (more lights: no culling for them)
-#define PTR_MANY_THRESHOLD 128     // more spheres than this: the LDS-staged kernel (ptr_kernels_many.hip)
+#define PTR_FAST_MAX_SPHERES 12    // up to this many spheres: ptr_kernels_fast.hip; more: ptr_kernels_many.hip (measured
+                                  //   crossover on MI355X: 7 spheres 0.35 vs 0.46 ms, 16 spheres 0.55 vs 0.40 ms per 16 frames)
+#define PTR_MANY_THRESHOLD 128     // ptr_kernels_many.hip: more spheres than this are staged through LDS, fewer come by scalar loads
 #define PTR_COUNTER_STRIDE 16     // uint32 words between two sub-queue counters (64 B)
 
 namespace ptr {
