@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include "ptr_device.h"
 #include "ptr_kernels.h"
+#include "ptr_fast_common.h"
 
 namespace ptr {
 
@@ -169,6 +170,141 @@ __device__ V<T> trace_ext(const SceneT<T>& sc, V<T> o0, V<T> d0, int max_depth, 
     return acc;
 }
 
+// ---- float32 throughput form of the same expansion -------------------------------------------------------
+// Same rays, same weights, same order as trace_ext<float>; what differs is how a wave gets through the sphere
+// loops (and, within float32 rounding, the arithmetic: rsq instead of 1/sqrt, FMA contraction by hand):
+//   * sphere records arrive by scalar loads (wave-uniform index, constant address space);
+//   * Sphere.intersect is evaluated branch-free for all lanes (b, disc), the root only when some lane hits;
+//   * the shadow loop first asks the (light, occluder) cone table of ptr_device.h (PairQ): the shadow ray runs
+//     along the line through the light's centre, so an occluder whose cone that line misses is skipped by the
+//     whole wave; lanes facing away from the light are not tested (their term is 0 either way); the loop ends
+//     when every lane is decided.
+typedef const f4 PTR_CONST* ConstRec;
+__device__ __forceinline__ bool any_lane_x(bool c) { return ballot(c) != 0ull; }
+
+__device__ V<float> trace_ext_f32(const unsigned char* block, const RenderArgs& a, V<float> o0, V<float> d0, int max_depth)
+{
+    const ConstHeader hdr = (ConstHeader)(uintptr_t)block;
+    const ConstRec rec0 = (ConstRec)(uintptr_t)(block + a.off_p32);
+    const ConstRec pairs0 = (ConstRec)(uintptr_t)(block + a.off_pairs);
+    const ConstM32 cm32 = (ConstM32)(uintptr_t)(block + a.off_m32);
+    const ConstI32 clights = (ConstI32)(uintptr_t)(block + a.off_lights);
+    const SphereP32* gp32 = reinterpret_cast<const SphereP32*>(block + a.off_p32);
+    const SphereM32* gm32 = reinterpret_cast<const SphereM32*>(block + a.off_m32);
+    const int n = a.n, nl = hdr->n_lights;
+    const float bgx = hdr->bg32[0], bgy = hdr->bg32[1], bgz = hdr->bg32[2];
+    constexpr float BIAS = (float)PTR_BIAS;
+
+    ExtRay<float> stack[PTR_EXT_MAX_DEPTH + 2];
+    int top = 1;
+    stack[0] = ExtRay<float>{o0, d0, V<float>{1, 1, 1}, 0};
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    while (top > 0) {
+        const ExtRay<float> r = stack[--top];
+        // nearest hit (RayTracer.js:26-41)
+        float tnear = (float)PTR_INFINITY;
+        int e = -1;
+        for (int i = 0; i < n; i++) {
+            const f4 g0 = rec0[4 * (size_t)i];
+            const float r2 = rec0[4 * (size_t)i + 1].z;
+            const float lx = g0.x - r.o.x, ly = g0.y - r.o.y, lz = g0.z - r.o.z;
+            const float b = fmaf(lz, r.d.z, fmaf(ly, r.d.y, lx * r.d.x));
+            const float ll = fmaf(lz, lz, fmaf(ly, ly, lx * lx));
+            const float disc = fmaf(b, b, r2 - ll);                       // radius2 - d2 (Sphere.js:21-27)
+            const bool hit = (b >= 0.0f) & (disc >= 0.0f);
+            if (any_lane_x(hit)) {
+                const float thc = disc * rsq(fmaxf(disc, 1e-30f));
+                float t = b - thc;
+                t = t < 0.0f ? b + thc : t;                               // RayTracer.js:32-34
+                const bool nearer = hit & (t < tnear);
+                tnear = nearer ? t : tnear;
+                e = nearer ? i : e;
+            }
+        }
+        if (e < 0) {
+            ax = fmaf(r.w.x, bgx, ax); ay = fmaf(r.w.y, bgy, ay); az = fmaf(r.w.z, bgz, az);
+            continue;
+        }
+        const SphereM32 m = gm32[e];
+        const float4 ce = *reinterpret_cast<const float4*>(&gp32[e].lx);
+        const float refl = gp32[e].refl, transp = gp32[e].transp;
+        ax = fmaf(r.w.x, m.er, ax); ay = fmaf(r.w.y, m.eg, ay); az = fmaf(r.w.z, m.eb, az);
+        const V<float> P{fmaf(r.d.x, tnear, r.o.x), fmaf(r.d.y, tnear, r.o.y), fmaf(r.d.z, tnear, r.o.z)};
+        V<float> N{P.x - ce.x, P.y - ce.y, P.z - ce.z};
+        {
+            const float inv = rsq(fmaf(N.z, N.z, fmaf(N.y, N.y, N.x * N.x)));
+            N.x *= inv; N.y *= inv; N.z *= inv;
+        }
+        float dn = fmaf(r.d.z, N.z, fmaf(r.d.y, N.y, r.d.x * N.x));
+        const bool inside = dn > 0.0f;
+        if (inside) { N.x = -N.x; N.y = -N.y; N.z = -N.z; dn = -dn; }
+        if ((transp > 0.0f || refl > 0.0f) && r.depth < max_depth) {
+            const float f = 1.0f + dn;                                    // 1 - facing, facing = -(d.N)
+            const float fresnel = fmaf(f * f * f, 0.9f, 0.1f);
+            const float wx = r.w.x * m.sr, wy = r.w.y * m.sg, wz = r.w.z * m.sb;
+            if (transp > 0.0f) {
+                const float eta = inside ? 1.1f : 1.0f / 1.1f;
+                const float cosi = -dn;
+                const float k2 = 1.0f - eta * eta * (1.0f - cosi * cosi);
+                if (k2 >= 0.0f) {
+                    ExtRay<float>& c = stack[top++];
+                    const float g = eta * cosi - __builtin_sqrtf(k2);
+                    const float wt = (1.0f - fresnel) * transp;
+                    c.o = V<float>{fmaf(-N.x, BIAS, P.x), fmaf(-N.y, BIAS, P.y), fmaf(-N.z, BIAS, P.z)};
+                    V<float> cd{fmaf(r.d.x, eta, N.x * g), fmaf(r.d.y, eta, N.y * g), fmaf(r.d.z, eta, N.z * g)};
+                    const float inv = rsq(fmaf(cd.z, cd.z, fmaf(cd.y, cd.y, cd.x * cd.x)));
+                    c.d = V<float>{cd.x * inv, cd.y * inv, cd.z * inv};
+                    c.w = V<float>{wx * wt, wy * wt, wz * wt};
+                    c.depth = r.depth + 1;
+                }
+            }
+            ExtRay<float>& c = stack[top++];
+            const float two = 2.0f * dn;
+            c.o = V<float>{fmaf(N.x, BIAS, P.x), fmaf(N.y, BIAS, P.y), fmaf(N.z, BIAS, P.z)};
+            V<float> cd{fmaf(-N.x, two, r.d.x), fmaf(-N.y, two, r.d.y), fmaf(-N.z, two, r.d.z)};
+            const float inv = rsq(fmaf(cd.z, cd.z, fmaf(cd.y, cd.y, cd.x * cd.x)));
+            c.d = V<float>{cd.x * inv, cd.y * inv, cd.z * inv};
+            c.w = V<float>{wx * fresnel, wy * fresnel, wz * fresnel};
+            c.depth = r.depth + 1;
+        } else {
+            // the reference's direct lighting (RayTracer.js:60-91)
+            const float sox = fmaf(N.x, BIAS, P.x), soy = fmaf(N.y, BIAS, P.y), soz = fmaf(N.z, BIAS, P.z);
+            float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+            for (int kk = 0; kk < nl; kk++) {
+                const int i = clights[kk];
+                const f4 lg = rec0[4 * (size_t)i];
+                const int prow = kk < PTR_MAX_PAIR_LIGHTS ? kk : (n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS);
+                const ConstRec pairs = pairs0 + (size_t)prow * (size_t)(n + 2);
+                float Lx = lg.x - P.x, Ly = lg.y - P.y, Lz = lg.z - P.z;
+                const float invl = rsq(fmaf(Lz, Lz, fmaf(Ly, Ly, Lx * Lx)));
+                Lx *= invl; Ly *= invl; Lz *= invl;
+                const float ratio = fmaf(N.z, Lz, fmaf(N.y, Ly, N.x * Lx));
+                bool open = ratio > 0.0f;                                 // max(0, N.L) = 0: the term vanishes either way
+                for (int j = 0; j < n; j++) {
+                    if (!any_lane_x(open)) break;
+                    if (j == i) continue;                                 // RayTracer.js:76
+                    const f4 pq = pairs[j];
+                    const float c = fmaf(pq.z, Lz, fmaf(pq.y, Ly, pq.x * Lx));
+                    if (!any_lane_x(open & (fabsf(c) + 1e-5f >= pq.w))) continue;
+                    const f4 g0 = rec0[4 * (size_t)j];
+                    const float r2 = rec0[4 * (size_t)j + 1].z;
+                    const float lx = g0.x - sox, ly = g0.y - soy, lz = g0.z - soz;
+                    const float b = fmaf(lz, Lz, fmaf(ly, Ly, lx * Lx));
+                    const float ll = fmaf(lz, lz, fmaf(ly, ly, lx * lx));
+                    const float disc = fmaf(b, b, r2 - ll);
+                    open = open & !((b >= 0.0f) & (disc >= 0.0f));        // any hit blocks; distance ignored (F7)
+                }
+                const float lit = open ? ratio : 0.0f;
+                dx = fmaf(m.sr * cm32[i].er, lit, dx);
+                dy = fmaf(m.sg * cm32[i].eg, lit, dy);
+                dz = fmaf(m.sb * cm32[i].eb, lit, dz);
+            }
+            ax = fmaf(r.w.x, dx, ax); ay = fmaf(r.w.y, dy, ay); az = fmaf(r.w.z, dz, az);
+        }
+    }
+    return V<float>{ax, ay, az};
+}
+
 // Philox4x32-10 (Salmon et al., SC'11); counter = (x, y, sample, 0), key = (seed, 'PTR!')
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t& r0, uint32_t& r1)
@@ -216,7 +352,14 @@ __device__ __forceinline__ void render_ext_pixel(const RenderArgs& a, int x, int
         }
         normalize_v(d);
         xcount<STATS>(k, XT_CAMERA);
-        const V<T> c = trace_ext<T, STATS>(sc, origin, d, a.max_depth, k);
+        V<T> c;
+        if constexpr (sizeof(T) == 4 && !STATS) {
+            const V<float> cf = trace_ext_f32(a.scenes + (uint64_t)(a.first_frame + frame) * a.frame_stride, a,
+                                              V<float>{0, 0, 0}, V<float>{(float)d.x, (float)d.y, (float)d.z}, a.max_depth);
+            c = V<T>{T(cf.x), T(cf.y), T(cf.z)};
+        } else {
+            c = trace_ext<T, STATS>(sc, origin, d, a.max_depth, k);
+        }
         sum.x += c.x; sum.y += c.y; sum.z += c.z;
     }
     if (a.spp > 1) { const T k = T(a.spp); sum.x /= k; sum.y /= k; sum.z /= k; }
