@@ -20,6 +20,7 @@
 #define PTR_FAST_MAX_SPHERES 12    // up to this many spheres: ptr_kernels_fast.hip; more: ptr_kernels_many.hip (measured
                                   //   crossover on MI355X: 7 spheres 0.35 vs 0.46 ms, 16 spheres 0.55 vs 0.40 ms per 16 frames)
 #define PTR_MANY_THRESHOLD 128     // ptr_kernels_many.hip: more spheres than this are staged through LDS, fewer come by scalar loads
+#define PTR_WIDE_RETRACE_MIN 256   // this many spheres or more: a whole wave re-traces one queued pixel
 #define PTR_COUNTER_STRIDE 16     // uint32 words between two sub-queue counters (64 B)
 
 namespace ptr {

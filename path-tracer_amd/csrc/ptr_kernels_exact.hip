@@ -212,6 +212,74 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_exact_kernel(RenderArgs a)
     }
 }
 
+// RayTracer.trace by a whole wave for ONE ray (scenes with many spheres): lane l tests elements l, l + 64, ...
+// Every test is the same float64 arithmetic as in trace_exact; the nearest hit is the minimum over lanes of
+// (t, index) — what the reference's strict '<' scan in scene order picks — and a shadow ray is blocked when any
+// lane finds a hit.  All lanes return the same colour.
+__device__ V3 trace_exact_wide(const FrameView& fv, V3 o, V3 d)
+{
+    const int n = fv.h->n, lane = threadIdx.x & 63;
+    double tnear = PTR_INFINITY;
+    int element = 0x7fffffff;
+    for (int i = lane; i < n; i += 64) {
+        const SphereG64 s = fv.g64[i];
+        double lx = s.cx - o.x, ly = s.cy - o.y, lz = s.cz - o.z;
+        double tca = lx * d.x + ly * d.y + lz * d.z;
+        if (tca < 0) continue;
+        double d2 = (lx * lx + ly * ly + lz * lz) - tca * tca;
+        if (d2 > s.r2) continue;
+        double thc = __builtin_sqrt(s.r2 - d2);
+        double t0 = tca - thc, t1 = tca + thc;
+        if (t0 < 0) t0 = t1;
+        if (t0 < tnear) { tnear = t0; element = i; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double t_o = __shfl_xor(tnear, off, 64);
+        const int e_o = __shfl_xor(element, off, 64);
+        if (t_o < tnear || (t_o == tnear && e_o < element)) { tnear = t_o; element = e_o; }
+    }
+    if (element == 0x7fffffff) return V3{fv.h->bg64[0], fv.h->bg64[1], fv.h->bg64[2]};   // RayTracer.js:43-46
+
+    const SphereG64 se = fv.g64[element];
+    const SphereM64 me = fv.m64[element];
+    V3 P{o.x + d.x * tnear, o.y + d.y * tnear, o.z + d.z * tnear};
+    V3 N{P.x - se.cx, P.y - se.cy, P.z - se.cz};
+    normalize_js(N);
+    if (d.x * N.x + d.y * N.y + d.z * N.z > 0) { N.x = -N.x; N.y = -N.y; N.z = -N.z; }
+    const V3 so{P.x + N.x * PTR_BIAS, P.y + N.y * PTR_BIAS, P.z + N.z * PTR_BIAS};
+    V3 acc{0, 0, 0};
+    const int nl = fv.h->n_lights;
+    for (int k = 0; k < nl; k++) {
+        const int i = fv.lights[k];
+        const SphereG64 li = fv.g64[i];
+        const SphereM64 lm = fv.m64[i];
+        V3 L{li.cx - P.x, li.cy - P.y, li.cz - P.z};
+        normalize_js(L);
+        double tr = 1.0;
+        for (int j0 = 0; j0 < n; j0 += 64) {                 // wave-uniform trip count
+            const int j = j0 + lane;
+            bool hit = false;
+            if (j < n && j != i) {
+                const SphereG64 s = fv.g64[j];
+                double lx = s.cx - so.x, ly = s.cy - so.y, lz = s.cz - so.z;
+                double tca = lx * L.x + ly * L.y + lz * L.z;
+                if (!(tca < 0)) {
+                    double d2 = (lx * lx + ly * ly + lz * lz) - tca * tca;
+                    hit = !(d2 > s.r2);
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(hit) != 0ull) { tr = 0.0; break; }
+        }
+        double ratio = js_max0(N.x * L.x + N.y * L.y + N.z * L.z);
+        acc.x += (me.sr * tr) * (lm.er * ratio);
+        acc.y += (me.sg * tr) * (lm.eg * ratio);
+        acc.z += (me.sb * tr) * (lm.eb * ratio);
+    }
+    acc.x += me.er; acc.y += me.eg; acc.z += me.eb;
+    return acc;
+}
+
 // hybrid mode, second kernel: the pixels the float32 kernel was not sure about.
 // One workgroup per (sub-queue, kind); the fill counts are read from device memory, so the host never
 // synchronises between the two kernels.  kind 0 (blockIdx.y == 0): re-trace the pixel from scratch;
@@ -229,6 +297,30 @@ __global__ void __launch_bounds__(PTR_BLOCK) retrace_exact_kernel(RenderArgs a)
     const uint32_t* queue = a.queue + (uint64_t)sub * a.queue_capacity;
     const uint32_t* qinfo = a.qinfo + 2 * (uint64_t)sub * a.queue_capacity;
     const uint64_t frame_px = (uint64_t)a.width * (uint64_t)a.scan_height;
+    if (kind == 0 && a.n >= PTR_WIDE_RETRACE_MIN) {
+        // many spheres: one wave per queued pixel (trace_exact_wide), waves of all the sub-queue's workgroups take turns
+        const uint32_t waves = (blockDim.x >> 6) * gridDim.z;
+        for (uint32_t q = blockIdx.z * (blockDim.x >> 6) + (threadIdx.x >> 6); q < count; q += waves) {
+            const uint64_t gid = queue[q];
+            if (gid >= frame_px * (uint64_t)a.n_frames) continue;
+            const int frame = (int)(gid / frame_px);
+            const uint32_t pix = (uint32_t)(gid - (uint64_t)frame * frame_px);
+            const int row = (int)(pix / (uint32_t)a.width), x = (int)(pix - (uint32_t)row * a.width);
+            const FrameView fv = frame_view(a.scenes + (uint64_t)(a.first_frame + frame) * a.frame_stride);
+            const V3 o{a.cam.org[0], a.cam.org[1], a.cam.org[2]};
+            const V3 c = trace_exact_wide(fv, o, primary_dir_exact(a.cam, x, global_y(a, row)));
+            if ((threadIdx.x & 63) == 0) {
+                const long long idx = store_index(a, x, row);
+                if (idx >= 0) a.out8[frame * a.out_frame_stride + idx] = pack_js(c.x, c.y, c.z);
+                if (a.out32f) {
+                    float* p = a.out32f + 4 * (frame * a.out_frame_stride + (uint64_t)a.width * row + x);
+                    p[0] = (float)c.x; p[1] = (float)c.y; p[2] = (float)c.z; p[3] = 1.0f;
+                }
+            }
+        }
+        if (threadIdx.x == 0 && blockIdx.z == 0 && a.stats) atomicAdd(&a.stats[ST_RETRACED], (unsigned long long)count);
+        return;
+    }
     // gridDim.z workgroups share a sub-queue (many spheres: an entry is long, spread them wide)
     for (uint32_t q = blockIdx.z * blockDim.x + threadIdx.x; q < count; q += blockDim.x * gridDim.z) {
         const uint32_t slot = kind ? a.queue_capacity - 1u - q : q;
