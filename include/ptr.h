@@ -222,6 +222,17 @@ int ptr_trace_batch_f64(ptr_ctx *ctx, const double *origins_xyz, const double *d
                         double *out_rgb64, int32_t *out_element,
                         double *out_hit_xyz, double *out_normal_xyz);
 
+/* Batched Sample.doRaytracing(raytracer, from, request) of the render cache (rendercache-js/src/Sample.js:49-75
+ * -> Raytracer.trace, rendercache-js/src/Raytracer.js:24-123), float64, op-for-op.  Every ray starts at
+ * origin_xyz (the cache's camera.from).  The colour arithmetic is that of RayTracer.trace; the outputs follow
+ * the render cache: out_rgb64 (nullable) = the unclamped colour trace() returns, out_rgb8 (nullable) = the three
+ * Math.round(Math.min(1, c) * 255) values of sample.color; out_hit_xyz (nullable) = sample.hit — the hit point,
+ * or origin + dir * 1e5 on a miss (Raytracer.js:62-68); out_normal_xyz (nullable) = sample.normalDir — the
+ * element's outward normal normalized a second time (Raytracer.js:75-76, NOT turned towards the ray), or -hit
+ * on a miss.  At least one of out_rgb64 / out_rgb8 must be given.  All HOST pointers.                    */
+int ptr_trace_samples_f64(ptr_ctx *ctx, const double origin_xyz[3], const double *dirs_xyz, int n,
+                          double *out_rgb64, uint8_t *out_rgb8, double *out_hit_xyz, double *out_normal_xyz);
+
 /* ---- introspection ----------------------------------------------------------------------- */
 int ptr_get_stats(ptr_ctx *ctx, ptr_stats *out);
 

@@ -49,6 +49,8 @@ def lib():
         L.orc_trace.restype = None
         L.orc_request_pixel.argtypes = [dp, C.c_int, dp, dp, dp]
         L.orc_request_pixel.restype = None
+        L.orc_trace_sample.argtypes = [dp, C.c_int, dp, dp, dp, dp, dp, dp, dp]
+        L.orc_trace_sample.restype = None
         L.orc_render.argtypes = [dp, C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32,
                                  C.POINTER(C.c_uint32), C.POINTER(Counters)]
         L.orc_render.restype = None
@@ -157,6 +159,21 @@ def trace_batch(soa, bg, origins, dirs):
         L.orc_trace(_dp(soa), soa.shape[1], _dp(bg), _dp(origins[k]), _dp(dirs[k]), _dp(tmp), C.byref(hit), None)
         rgb[k] = tmp; el[k] = hit.element; pt[k] = hit.point[:]; nr[k] = hit.normal[:]; tn[k] = hit.tnear
     return rgb, el, pt, nr, tn
+
+
+def trace_samples(soa, bg, origins, dirs):
+    """render-cache samples: returns (rgb[n,3], rgb8[n,3], hit[n,3], normal[n,3]); origins (3,) or (n,3)"""
+    soa = np.ascontiguousarray(soa, dtype=np.float64)
+    bg = np.ascontiguousarray(bg, dtype=np.float64)
+    dirs = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
+    n = dirs.shape[0]
+    origins = np.ascontiguousarray(np.broadcast_to(np.asarray(origins, dtype=np.float64).reshape(-1, 3), (n, 3)))
+    out = [np.empty((n, 3)) for _ in range(4)]
+    L = lib()
+    for k in range(n):
+        L.orc_trace_sample(_dp(soa), soa.shape[1], _dp(bg), _dp(origins[k]), _dp(dirs[k]),
+                           _dp(out[0][k]), _dp(out[1][k]), _dp(out[2][k]), _dp(out[3][k]))
+    return tuple(out)
 
 
 def request_pixel(soa, bg, d):

@@ -161,6 +161,28 @@ void orc_trace(const double *soa, int n, const double bg[3],
     rgb[0] = acc[0]; rgb[1] = acc[1]; rgb[2] = acc[2];
 }
 
+/* ---- rendercache-js: Sample.doRaytracing -> Raytracer.trace (RC/src/Sample.js:49-75, RC/src/Raytracer.js:24-123) --
+ * Same colour arithmetic as RayTracer.trace; the render cache also keeps sample.hit and sample.normalDir:
+ * miss: hit = o + d * 1e5, normalDir = -hit (:62-68); hit: the hit point and the element's outward normal
+ * normalized a second time, before it is turned towards the ray (:71-76). */
+void orc_trace_sample(const double *soa, int n, const double bg[3], const double o[3], const double d[3],
+                      double rgb[3], double rgb8[3], double hit_xyz[3], double normal_xyz[3])
+{
+    orc_hit h;
+    orc_trace(soa, n, bg, o, d, rgb, &h, 0);
+    if (h.element < 0) {
+        for (int a = 0; a < 3; a++) { hit_xyz[a] = o[a] + d[a] * 100000.0; normal_xyz[a] = -hit_xyz[a]; }
+    } else {
+        const double *cx = PL(0), *cy = PL(1), *cz = PL(2);
+        double N[3] = { h.point[0] - cx[h.element], h.point[1] - cy[h.element], h.point[2] - cz[h.element] };
+        v_normalize(N);
+        v_normalize(N);
+        memcpy(hit_xyz, h.point, sizeof h.point);
+        memcpy(normal_xyz, N, sizeof N);
+    }
+    for (int a = 0; a < 3; a++) rgb8[a] = js_round(js_min1(rgb[a]) * 255.0);
+}
+
 /* ---- RayTracer.requestPixel (RayTracer.js:98-115) ---------------------------------------- */
 void orc_request_pixel(const double *soa, int n, const double bg[3], const double d[3], double rgb[3])
 {

@@ -625,11 +625,11 @@ int ptr_render(ptr_ctx* c, const ptr_params* p, uint32_t* out_rgba8, float* out_
     return PTR_OK;
 }
 
-int ptr_trace_batch_f64(ptr_ctx* c, const double* origins, const double* dirs, int n,
-                        double* out_rgb, int32_t* out_element, double* out_hit, double* out_normal)
+// shared body of the batched single-ray entries; org = origin of every ray when origins == NULL;
+// rc = the render cache's output convention (ptr_trace_samples_f64).  Caller holds c->mu.
+static int trace_batch_locked(ptr_ctx* c, const double* origins, const double org[3], const double* dirs, int n,
+                              double* out_rgb, int32_t* out_element, double* out_hit, double* out_normal, bool rc)
 {
-    if (!c) return PTR_ERR_INVALID;
-    std::lock_guard<std::mutex> g(c->mu);
     if (!c->have_scene) return fail(c, PTR_ERR_NO_SCENE, "no scene uploaded (call ptr_set_scene* first)");
     if (n < 0) return fail(c, PTR_ERR_INVALID, "n < 0");
     if (n == 0) return PTR_OK;
@@ -652,7 +652,8 @@ int ptr_trace_batch_f64(ptr_ctx* c, const double* origins, const double* dirs, i
     a.origins = origins ? static_cast<const double*>(c->tr_in_o.ptr) : nullptr;
     a.dirs = static_cast<const double*>(c->tr_in_d.ptr);
     a.n = n;
-    for (int k = 0; k < 3; k++) a.org[k] = c->cam.origin[k];
+    for (int k = 0; k < 3; k++) a.org[k] = org[k];
+    a.rc_mode = rc ? 1 : 0;
     a.out_rgb = static_cast<double*>(c->tr_rgb.ptr);
     a.out_element = out_element ? static_cast<int32_t*>(c->tr_el.ptr) : nullptr;
     a.out_hit = out_hit ? static_cast<double*>(c->tr_hit.ptr) : nullptr;
@@ -663,6 +664,34 @@ int ptr_trace_batch_f64(ptr_ctx* c, const double* origins, const double* dirs, i
     if (out_hit) HIP_TRY(c, hipMemcpyAsync(out_hit, c->tr_hit.ptr, v3, hipMemcpyDeviceToHost, s));
     if (out_normal) HIP_TRY(c, hipMemcpyAsync(out_normal, c->tr_nrm.ptr, v3, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    return PTR_OK;
+}
+
+int ptr_trace_batch_f64(ptr_ctx* c, const double* origins, const double* dirs, int n,
+                        double* out_rgb, int32_t* out_element, double* out_hit, double* out_normal)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    return trace_batch_locked(c, origins, c->cam.origin, dirs, n, out_rgb, out_element, out_hit, out_normal, false);
+}
+
+int ptr_trace_samples_f64(ptr_ctx* c, const double origin_xyz[3], const double* dirs_xyz, int n,
+                          double* out_rgb64, uint8_t* out_rgb8, double* out_hit_xyz, double* out_normal_xyz)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!origin_xyz) return fail(c, PTR_ERR_INVALID, "origin_xyz is NULL");
+    if (n > 0 && !out_rgb64 && !out_rgb8) return fail(c, PTR_ERR_INVALID, "out_rgb64 and out_rgb8 are both NULL");
+    std::vector<double> tmp;
+    double* rgb = out_rgb64;
+    if (!rgb && n > 0) {
+        try { tmp.resize((size_t)n * 3); } catch (const std::bad_alloc&) { return fail(c, PTR_ERR_INVALID, "out of host memory"); }
+        rgb = tmp.data();
+    }
+    PTR_TRY(trace_batch_locked(c, nullptr, origin_xyz, dirs_xyz, n, rgb, nullptr, out_hit_xyz, out_normal_xyz, true));
+    if (out_rgb8)                                   // Sample.js:57-65: Math.round(Math.min(1, c) * 255)
+        for (size_t k = 0; k < (size_t)n * 3; k++)
+            out_rgb8[k] = (uint8_t)(js_to_uint32(js_round(js_min1(rgb[k]) * 255.0)) & 0xffu);
     return PTR_OK;
 }
 

@@ -144,6 +144,7 @@ struct TraceArgs {
     const double* origins;           // nullable -> cam origin
     const double* dirs;
     int32_t n;
+    int32_t rc_mode;                 // 1: outputs follow rendercache-js (ptr_trace_samples_f64)
     double org[3];
     double* out_rgb;                 // 3 per ray
     int32_t* out_element;            // nullable

@@ -361,6 +361,20 @@ __global__ void __launch_bounds__(PTR_BLOCK) trace_batch_exact_kernel(TraceArgs 
     V3 d{a.dirs[3 * k], a.dirs[3 * k + 1], a.dirs[3 * k + 2]};
     ExactHit h;
     V3 c = trace_exact<false>(fv, o, d, &h, nullptr);
+    if (a.rc_mode) {
+        // rendercache-js/src/Raytracer.js:62-76: a miss reports a point 1e5 along the ray and normalDir = -hit;
+        // a hit reports the geometric normal BEFORE it is turned towards the ray, normalized a second time
+        if (h.element < 0) {
+            h.P = V3{o.x + d.x * 100000.0, o.y + d.y * 100000.0, o.z + d.z * 100000.0};
+            h.N = V3{-h.P.x, -h.P.y, -h.P.z};
+        } else {
+            const SphereG64 se = fv.g64[h.element];
+            V3 N{h.P.x - se.cx, h.P.y - se.cy, h.P.z - se.cz};
+            normalize_js(N);
+            normalize_js(N);
+            h.N = N;
+        }
+    }
     a.out_rgb[3 * k] = c.x; a.out_rgb[3 * k + 1] = c.y; a.out_rgb[3 * k + 2] = c.z;
     if (a.out_element) a.out_element[k] = h.element;
     if (a.out_hit) { a.out_hit[3 * k] = h.P.x; a.out_hit[3 * k + 1] = h.P.y; a.out_hit[3 * k + 2] = h.P.z; }

@@ -13,6 +13,7 @@
  *   setCamera(h, Float64Array(13) | null)                                    ptr_set_camera
  *   render(h, w, height, startY, scanHeight, flags)  -> ArrayBuffer (RGBA8)  ptr_render
  *   renderAsync(h, w, height, startY, scanHeight, flags) -> Promise<ArrayBuffer>
+ *   traceSamples(h, Float64Array origin(3), Float64Array dirs) -> {rgb, rgb8, hit, normal}   ptr_trace_samples_f64
  *   traceBatch(h, Float64Array origins | null, Float64Array dirs)
  *        -> { rgb: Float64Array, element: Int32Array, hit: Float64Array, normal: Float64Array }
  *                                                                            ptr_trace_batch_f64
@@ -372,6 +373,42 @@ static napi_value js_trace_batch(napi_env env, napi_callback_info info)
     return out;
 }
 
+/* traceSamples(h, Float64Array origin(3), Float64Array dirs) -> {rgb, rgb8, hit, normal}: the render cache's
+ * Sample.doRaytracing, batched (ptr_trace_samples_f64) */
+static napi_value js_trace_samples(napi_env env, napi_callback_info info)
+{
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return NULL;
+    ptr_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    double *org, *dir; size_t no, nd;
+    if (!get_f64_array(env, argv[1], &org, &no) || !get_f64_array(env, argv[2], &dir, &nd)) return NULL;
+    if (!org || no != 3 || !dir || nd % 3 != 0) {
+        napi_throw_range_error(env, "PTR_ERR_INVALID", "origin must hold 3 numbers and dirs 3*n");
+        return NULL;
+    }
+    size_t n = nd / 3;
+    if (n > 0x3fffffff) { napi_throw_range_error(env, "PTR_ERR_INVALID", "too many rays"); return NULL; }
+    napi_value ab_rgb, ab_b, ab_hit, ab_nrm, rgb, b8, hit, nrm, out;
+    void *d_rgb, *d_b, *d_hit, *d_nrm;
+    NAPI_TRY(env, napi_create_arraybuffer(env, n * 3 * sizeof(double), &d_rgb, &ab_rgb));
+    NAPI_TRY(env, napi_create_arraybuffer(env, n * 3, &d_b, &ab_b));
+    NAPI_TRY(env, napi_create_arraybuffer(env, n * 3 * sizeof(double), &d_hit, &ab_hit));
+    NAPI_TRY(env, napi_create_arraybuffer(env, n * 3 * sizeof(double), &d_nrm, &ab_nrm));
+    int rc = ptr_trace_samples_f64(ctx, org, dir, (int)n, (double *)d_rgb, (uint8_t *)d_b, (double *)d_hit, (double *)d_nrm);
+    if (rc != PTR_OK) return throw_ptr(env, ctx, rc);
+    NAPI_TRY(env, napi_create_typedarray(env, napi_float64_array, n * 3, ab_rgb, 0, &rgb));
+    NAPI_TRY(env, napi_create_typedarray(env, napi_uint8_array, n * 3, ab_b, 0, &b8));
+    NAPI_TRY(env, napi_create_typedarray(env, napi_float64_array, n * 3, ab_hit, 0, &hit));
+    NAPI_TRY(env, napi_create_typedarray(env, napi_float64_array, n * 3, ab_nrm, 0, &nrm));
+    NAPI_TRY(env, napi_create_object(env, &out));
+    NAPI_TRY(env, napi_set_named_property(env, out, "rgb", rgb));
+    NAPI_TRY(env, napi_set_named_property(env, out, "rgb8", b8));
+    NAPI_TRY(env, napi_set_named_property(env, out, "hit", hit));
+    NAPI_TRY(env, napi_set_named_property(env, out, "normal", nrm));
+    return out;
+}
+
 static napi_value js_stats(napi_env env, napi_callback_info info)
 {
     napi_value argv[1];
@@ -397,7 +434,7 @@ NAPI_MODULE_INIT()
     const struct { const char *name; napi_callback fn; } fns[] = {
         {"create", js_create}, {"destroy", js_destroy}, {"setScene", js_set_scene},
         {"setBackground", js_set_background}, {"setCamera", js_set_camera}, {"render", js_render},
-        {"renderAsync", js_render_async}, {"traceBatch", js_trace_batch}, {"stats", js_stats},
+        {"renderAsync", js_render_async}, {"traceBatch", js_trace_batch}, {"traceSamples", js_trace_samples}, {"stats", js_stats},
     };
     for (size_t k = 0; k < sizeof fns / sizeof fns[0]; k++) {
         napi_value f;

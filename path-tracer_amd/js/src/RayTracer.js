@@ -138,6 +138,17 @@ export default class RayTracer {
         return this._native.traceBatch(this._handle, origins, dirs);
     }
 
+    /**
+     * The render cache's Sample.doRaytracing, batched (rendercache-js/src/Sample.js:49-75 -> Raytracer.js:24-123):
+     * every ray starts at `from` (a Vector3, the cache's camera.from); returns {rgb, rgb8, hit, normal} with 3
+     * numbers per ray — hit = the hit point or from + dir * 1e5 on a miss, normal = sample.normalDir (the outward
+     * normal, or -hit on a miss).
+     */
+    traceSamples(from, dirs) {
+        this._upload(false);
+        return this._native.traceSamples(this._handle, Float64Array.of(from.x, from.y, from.z), dirs);
+    }
+
     /** trace(rayOrigin, rayDir, depth) -> Vector3; depth is ignored, as in the reference (F1). */
     trace(rayOrigin, rayDir, depth) {
         const r = this.traceBatch(Float64Array.of(rayOrigin.x, rayOrigin.y, rayOrigin.z),

@@ -198,6 +198,33 @@ async function gpuTests() {
         assert.ok(off <= 0.005 * a.length, `float32: ${off} bytes off by more than 1/255`);
         f32.dispose();
     });
+    test('traceSamples(): the render cache\'s per-sample trace, bit for bit (rendercache-js goldens)', () => {
+        const rc = JSON.parse(fs.readFileSync(path.join(golden, 'rc', 'index.json')));
+        for (const name of ['rc_scene2', 'example1']) {
+            const desc = rc.scenes[name];
+            const rec = f64(path.join('rc', rc.samples[name].file));
+            const rt = new RayTracer(new Vector3(...desc.background), sceneFrom(desc), undefined, { mode: 'exact' });
+            const n = rec.length / 18;
+            // rays are grouped by origin in the file
+            let k0 = 0;
+            while (k0 < n) {
+                let k1 = k0;
+                while (k1 < n && rec[18 * k1] === rec[18 * k0] && rec[18 * k1 + 1] === rec[18 * k0 + 1] && rec[18 * k1 + 2] === rec[18 * k0 + 2]) k1++;
+                const dirs = new Float64Array(3 * (k1 - k0));
+                for (let k = k0; k < k1; k++) for (let a = 0; a < 3; a++) dirs[3 * (k - k0) + a] = rec[18 * k + 3 + a];
+                const out = rt.traceSamples(new Vector3(rec[18 * k0], rec[18 * k0 + 1], rec[18 * k0 + 2]), dirs);
+                for (let k = k0; k < k1; k++) for (let a = 0; a < 3; a++) {
+                    const j = 3 * (k - k0) + a;
+                    assert.strictEqual(out.rgb[j], rec[18 * k + 6 + a]);
+                    assert.strictEqual(out.hit[j], rec[18 * k + 9 + a]);
+                    assert.strictEqual(out.normal[j], rec[18 * k + 12 + a]);
+                    assert.strictEqual(out.rgb8[j], rec[18 * k + 15 + a]);
+                }
+                k0 = k1;
+            }
+            rt.dispose();
+        }
+    });
     test('argument validation', () => {
         const rt = new RayTracer(new Vector3(2, 2, 2), buildExample1());
         assert.throws(() => rt.render(0, 10), RangeError);

@@ -28,7 +28,7 @@ SYMBOLS = [
     "ptr_set_scene", "ptr_set_scene_f64", "ptr_set_scene_sequence_f64",
     "ptr_set_background", "ptr_set_background_f64", "ptr_set_camera",
     "ptr_render", "ptr_render_device", "ptr_render_strips_device", "ptr_strip_rows", "ptr_sync",
-    "ptr_trace_batch", "ptr_trace_batch_f64", "ptr_get_stats", "ptr_get_kernel_ms",
+    "ptr_trace_batch", "ptr_trace_batch_f64", "ptr_trace_samples_f64", "ptr_get_stats", "ptr_get_kernel_ms",
 ]
 
 
@@ -119,6 +119,7 @@ def lib():
         L.ptr_sync.argtypes = [vp]
         L.ptr_trace_batch.argtypes = [vp, fp, C.c_int, C.POINTER(C.c_uint8), fp, fp]
         L.ptr_trace_batch_f64.argtypes = [vp, dp, dp, C.c_int, dp, C.POINTER(C.c_int32), dp, dp]
+        L.ptr_trace_samples_f64.argtypes = [vp, dp, dp, C.c_int, dp, C.POINTER(C.c_uint8), dp, dp]
         L.ptr_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.ptr_get_kernel_ms.argtypes = [vp, fp, fp]
         _lib = L
@@ -248,6 +249,16 @@ class Renderer:
             self._h, _dp(origins) if origins is not None else None, _dp(dirs), n, _dp(rgb),
             el.ctypes.data_as(C.POINTER(C.c_int32)), _dp(hit), _dp(nrm)))
         return (rgb, el, hit, nrm) if want_hit else rgb
+
+    def trace_samples(self, origin, dirs):
+        """render-cache samples: returns (rgb64[n,3], rgb8[n,3], hit[n,3], normal[n,3])"""
+        dirs = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
+        origin = np.ascontiguousarray(origin, dtype=np.float64).reshape(3)
+        n = dirs.shape[0]
+        rgb = np.empty((n, 3)); rgb8 = np.empty((n, 3), dtype=np.uint8); hit = np.empty((n, 3)); nrm = np.empty((n, 3))
+        self._check(self._L.ptr_trace_samples_f64(self._h, _dp(origin), _dp(dirs), n, _dp(rgb),
+                                                  rgb8.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(hit), _dp(nrm)))
+        return rgb, rgb8, hit, nrm
 
     def trace_batch(self, dirs, want_hit=False):
         dirs = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
