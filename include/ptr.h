@@ -233,6 +233,37 @@ int ptr_trace_batch_f64(ptr_ctx *ctx, const double *origins_xyz, const double *d
 int ptr_trace_samples_f64(ptr_ctx *ctx, const double origin_xyz[3], const double *dirs_xyz, int n,
                           double *out_rgb64, uint8_t *out_rgb8, double *out_hit_xyz, double *out_normal_xyz);
 
+/* ---- render cache: reprojection pass ------------------------------------------------- */
+
+/* The camera state Camera.reprojectPixel reads (rendercache-js/src/Camera.js:52-74): camera.from and the two
+ * matrices of its THREE.PerspectiveCamera at that moment, as THREE.Matrix4.elements (column-major):
+ * view = cam.matrixWorldInverse, proj = cam.projectionMatrix; width/height = camera.scope.                 */
+typedef struct ptr_rc_camera {
+    double  from[3];
+    double  view[16];
+    double  proj[16];
+    int32_t width, height;
+} ptr_rc_camera;
+
+/* Replaces Driver.reprojectFrame() (rendercache-js/src/Driver.js:417-486, with detachFrameFromCache :405-416 and
+ * Camera.reprojectPixel), float64, same results as the reference's sequential walk over the cache:
+ *   hit_xyz        3 doubles per cache item (cacheItem.hit); NaN in x = the item has no hit
+ *   age            cacheItem.age, updated in place (+age_factor loser / displaced winner, +2 outside the frame,
+ *                  +4 reprojection failed, i.e. depth 0)
+ *   item_pixel     out: cacheItem.pixel as y * (width + 2) + x on the padded grid of Driver.allocBuffers, or -1
+ *                  (an item displaced by a nearer one later in cache order keeps its pointer, as in the reference)
+ *   pixel_element  out: pixel.element as a cache index or -1;  pixel_depth  out: pixel.depth
+ * The pixel arrays hold (width + 2) * (height + 2) entries; only the interior 1..width x 1..height is written.
+ * age_factor = Driver.ageFactor (1), depth_threshold = Driver.depthThreshold (1e6).  No scene is needed.
+ * ptr_rc_reproject takes HOST pointers and waits; ptr_rc_reproject_device takes DEVICE pointers and only enqueues
+ * on `stream` (NULL = the context's stream).                                                                   */
+int ptr_rc_reproject(ptr_ctx *ctx, const ptr_rc_camera *camera, int n_items, const double *hit_xyz, double *age,
+                     double age_factor, double depth_threshold, int32_t *item_pixel, int32_t *pixel_element,
+                     double *pixel_depth);
+int ptr_rc_reproject_device(ptr_ctx *ctx, const ptr_rc_camera *camera, int n_items, const void *d_hit_xyz, void *d_age,
+                            double age_factor, double depth_threshold, void *d_item_pixel, void *d_pixel_element,
+                            void *d_pixel_depth, void *stream);
+
 /* ---- introspection ----------------------------------------------------------------------- */
 int ptr_get_stats(ptr_ctx *ctx, ptr_stats *out);
 

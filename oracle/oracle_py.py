@@ -69,6 +69,9 @@ def lib():
         L.orc_count_ext.restype = None
         L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.orc_philox4x32_10.restype = None
+        ip = C.POINTER(C.c_int32)
+        L.orc_rc_reproject_frame.argtypes = [dp, dp, dp, C.c_int, C.c_int, C.c_int, dp, dp, C.c_double, C.c_double, ip, ip, dp]
+        L.orc_rc_reproject_frame.restype = None
         L.orc_pack.argtypes = [dp]
         L.orc_pack.restype = C.c_uint32
         L.orc_reference_angle.restype = C.c_double
@@ -237,3 +240,20 @@ def philox(ctr, key):
     c = (C.c_uint32 * 4)(*ctr); k = (C.c_uint32 * 2)(*key); o = (C.c_uint32 * 4)()
     lib().orc_philox4x32_10(c, k, o)
     return list(o)
+
+
+# ---- render cache: reprojection pass ------------------------------------------------------------------------
+def rc_reproject(cam_from, view, proj, width, height, hits, age, age_factor=1.0, depth_threshold=1e6):
+    """returns (age_out[n], item_pixel[n], pixel_element[(h+2)*(w+2)], pixel_depth[(h+2)*(w+2)]); grid borders hold
+    -2 / NaN (never written, as in the reference)"""
+    cam_from = np.ascontiguousarray(cam_from, dtype=np.float64); view = np.ascontiguousarray(view, dtype=np.float64)
+    proj = np.ascontiguousarray(proj, dtype=np.float64); hits = np.ascontiguousarray(hits, dtype=np.float64).reshape(-1, 3)
+    n = hits.shape[0]
+    age = np.array(age, dtype=np.float64, copy=True)
+    item_pixel = np.empty(n, dtype=np.int32)
+    cells = (width + 2) * (height + 2)
+    el = np.full(cells, -2, dtype=np.int32); dep = np.full(cells, np.nan)
+    ip = C.POINTER(C.c_int32)
+    lib().orc_rc_reproject_frame(_dp(cam_from), _dp(view), _dp(proj), width, height, n, _dp(hits), _dp(age), age_factor,
+                                 depth_threshold, item_pixel.ctypes.data_as(ip), el.ctypes.data_as(ip), _dp(dep))
+    return age, item_pixel, el, dep

@@ -490,3 +490,66 @@ void orc_count_ext(const double *soa, int n, const double bg[3],
     ext_job j = { soa, n, bg, width, height, start_y, scan_height, max_depth, spp < 1 ? 1 : spp, seed, 0, 0, 0, 1, cnt, secondary };
     ext_main(&j);
 }
+
+
+/* ======================= rendercache-js: reprojection pass ===========================
+ * Driver.reprojectFrame (RC/src/Driver.js:417-486) with Camera.reprojectPixel (RC/src/Camera.js:52-74) and the
+ * three.js r139 arithmetic it calls (Vector3.project = applyMatrix4(matrixWorldInverse).applyMatrix4(projectionMatrix),
+ * each with its own perspective divide; RC/js/three.js Vector3.applyMatrix4).  Matrices are column-major as in
+ * THREE.Matrix4.elements.  Sequential, item order = cache order, exactly as the reference. */
+static void three_apply_matrix4(double v[3], const double e[16])
+{
+    const double x = v[0], y = v[1], z = v[2];
+    const double w = 1 / (e[3] * x + e[7] * y + e[11] * z + e[15]);
+    v[0] = (e[0] * x + e[4] * y + e[8] * z + e[12]) * w;
+    v[1] = (e[1] * x + e[5] * y + e[9] * z + e[13]) * w;
+    v[2] = (e[2] * x + e[6] * y + e[10] * z + e[14]) * w;
+}
+
+/* Camera.reprojectPixel: returns 0 when depth === 0; x, y are the Math.round()ed numbers (may be NaN/Inf) */
+int orc_rc_reproject_pixel(const double from[3], const double view[16], const double proj[16], int width, int height,
+                           const double hit[3], double *x, double *y, double *depth)
+{
+    const double dx = hit[0] - from[0], dy = hit[1] - from[1], dz = hit[2] - from[2];
+    *depth = sqrt(dx * dx + dy * dy + dz * dz);
+    double v[3] = { hit[0], hit[1], hit[2] };
+    three_apply_matrix4(v, view);
+    three_apply_matrix4(v, proj);
+    const double hx = 0.5 * width, hy = 0.5 * height;
+    *x = js_round(v[0] * hx + hx);
+    *y = js_round(v[1] * hy + hy);
+    return *depth == 0 ? 0 : 1;
+}
+
+void orc_rc_reproject_frame(const double from[3], const double view[16], const double proj[16], int width, int height,
+                            int n_items, const double *hit_xyz /* NaN x = no hit */, double *age, double age_factor,
+                            double depth_threshold, int32_t *item_pixel, int32_t *pixel_element, double *pixel_depth)
+{
+    const int stride = width + 2;
+    /* detachFrameFromCache (:405-416): interior pixels only */
+    for (int y = 1; y <= height; y++)
+        for (int x = 1; x <= width; x++) { pixel_element[y * stride + x] = -1; pixel_depth[y * stride + x] = depth_threshold; }
+    for (int i = 0; i < n_items; i++) {
+        item_pixel[i] = -1;                                         /* cacheItem.pixel = null */
+        const double *h = hit_xyz + 3 * (size_t)i;
+        if (h[0] != h[0]) continue;                                 /* cacheItem.hit === null */
+        double x, y, depth;
+        if (orc_rc_reproject_pixel(from, view, proj, width, height, h, &x, &y, &depth)) {
+            if (x >= 1 && x <= width && y >= 1 && y <= height) {
+                const int p = (int)y * stride + (int)x;
+                if (depth < pixel_depth[p]) {
+                    if (pixel_element[p] >= 0) age[pixel_element[p]] += age_factor;
+                    item_pixel[i] = p;                              /* attach: item.pixel = pixel, pixel.element = item */
+                    pixel_element[p] = i;
+                    pixel_depth[p] = depth;
+                } else {
+                    age[i] += age_factor;
+                }
+            } else {
+                age[i] += age_factor * 2;
+            }
+        } else {
+            age[i] += age_factor * 4;
+        }
+    }
+}

@@ -64,6 +64,8 @@ struct ptr_ctx {
     bool words_dirty = true;           // counters/stats must be zeroed before the next use
     DeviceBuffer out8, out32f;         // staging for ptr_render
     DeviceBuffer tr_in_o, tr_in_d, tr_rgb, tr_el, tr_hit, tr_nrm;   // staging for ptr_trace_batch*
+    DeviceBuffer rc_depth, rc_keys, rc_temp;                         // scratch of ptr_rc_reproject*
+    DeviceBuffer rc_hit, rc_age, rc_item, rc_pel, rc_pdep;           // staging for ptr_rc_reproject (host buffers)
     std::vector<unsigned char> host_blocks;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // PTR_FLAG_TIMING
     int timed_kernels = 0;             // kernels bracketed by ev[] in the last timed call
@@ -714,6 +716,91 @@ int ptr_trace_batch(ptr_ctx* c, const float* dirs_xyz, int n,
         out_rgb[k] = (uint8_t)(js_to_uint32(js_round(js_min1(rgb[k]) * 255.0)) & 0xffu);
     for (size_t k = 0; k < hit.size(); k++) out_hit_xyz[k] = (float)hit[k];
     for (size_t k = 0; k < nrm.size(); k++) out_normal_xyz[k] = (float)nrm[k];
+    return PTR_OK;
+}
+
+namespace {
+int rc_check(ptr_ctx* c, const ptr_rc_camera* cam, int n_items, const void* hit, const void* age, const void* item_pixel,
+             const void* pel, const void* pdep)
+{
+    if (!cam) return fail(c, PTR_ERR_INVALID, "camera is NULL");
+    if (cam->width < 1 || cam->height < 1 || (long long)(cam->width + 2) * (cam->height + 2) >= (1ll << 31))
+        return fail(c, PTR_ERR_INVALID, "bad frame size %d x %d", cam->width, cam->height);
+    if (n_items < 0) return fail(c, PTR_ERR_INVALID, "n_items < 0");
+    if (!pel || !pdep || (n_items > 0 && (!hit || !age || !item_pixel)))
+        return fail(c, PTR_ERR_INVALID, "a required buffer is NULL");
+    return PTR_OK;
+}
+
+// enqueue the pass on stream s; all data pointers are device memory.  Caller holds c->mu.
+int rc_enqueue(ptr_ctx* c, const ptr_rc_camera* cam, int n_items, const double* d_hit, double* d_age, double age_factor,
+               double depth_threshold, int32_t* d_item_pixel, int32_t* d_pel, double* d_pdep, hipStream_t s)
+{
+    const size_t n = (size_t)(n_items > 0 ? n_items : 1);
+    PTR_TRY(grow(c, c->rc_depth, n * sizeof(double)));
+    PTR_TRY(grow(c, c->rc_keys, 4 * n * sizeof(uint32_t)));
+    const size_t temp = rc_sort_temp_bytes(n_items > 0 ? n_items : 1, cam->width, cam->height);
+    PTR_TRY(grow(c, c->rc_temp, temp > 0 ? temp : 16));
+    RcArgs a;
+    std::memset(&a, 0, sizeof a);
+    std::memcpy(a.from, cam->from, sizeof a.from);
+    std::memcpy(a.view, cam->view, sizeof a.view);
+    std::memcpy(a.proj, cam->proj, sizeof a.proj);
+    a.width = cam->width; a.height = cam->height; a.n_items = n_items;
+    a.age_factor = age_factor; a.depth_threshold = depth_threshold;
+    a.hit_xyz = d_hit; a.age = d_age; a.item_pixel = d_item_pixel; a.pixel_element = d_pel; a.pixel_depth = d_pdep;
+    a.item_depth = static_cast<double*>(c->rc_depth.ptr);
+    uint32_t* k = static_cast<uint32_t*>(c->rc_keys.ptr);
+    a.sort_key = k; a.sort_val = k + n; a.sorted_key = k + 2 * n; a.sorted_val = k + 3 * n;
+    HIP_TRY(c, launch_rc_reproject(a, c->rc_temp.ptr, c->rc_temp.bytes, s));
+    return PTR_OK;
+}
+}  // namespace
+
+int ptr_rc_reproject_device(ptr_ctx* c, const ptr_rc_camera* cam, int n_items, const void* d_hit_xyz, void* d_age,
+                            double age_factor, double depth_threshold, void* d_item_pixel, void* d_pixel_element,
+                            void* d_pixel_depth, void* stream)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    PTR_TRY(rc_check(c, cam, n_items, d_hit_xyz, d_age, d_item_pixel, d_pixel_element, d_pixel_depth));
+    HIP_TRY(c, hipSetDevice(c->device));
+    return rc_enqueue(c, cam, n_items, static_cast<const double*>(d_hit_xyz), static_cast<double*>(d_age), age_factor,
+                      depth_threshold, static_cast<int32_t*>(d_item_pixel), static_cast<int32_t*>(d_pixel_element),
+                      static_cast<double*>(d_pixel_depth), stream ? static_cast<hipStream_t>(stream) : c->stream);
+}
+
+int ptr_rc_reproject(ptr_ctx* c, const ptr_rc_camera* cam, int n_items, const double* hit_xyz, double* age,
+                     double age_factor, double depth_threshold, int32_t* item_pixel, int32_t* pixel_element, double* pixel_depth)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    PTR_TRY(rc_check(c, cam, n_items, hit_xyz, age, item_pixel, pixel_element, pixel_depth));
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = (size_t)n_items, cells = (size_t)(cam->width + 2) * (size_t)(cam->height + 2);
+    PTR_TRY(grow(c, c->rc_hit, (n ? n : 1) * 3 * sizeof(double)));
+    PTR_TRY(grow(c, c->rc_age, (n ? n : 1) * sizeof(double)));
+    PTR_TRY(grow(c, c->rc_item, (n ? n : 1) * sizeof(int32_t)));
+    PTR_TRY(grow(c, c->rc_pel, cells * sizeof(int32_t)));
+    PTR_TRY(grow(c, c->rc_pdep, cells * sizeof(double)));
+    hipStream_t s = c->stream;
+    if (n) {
+        HIP_TRY(c, hipMemcpyAsync(c->rc_hit.ptr, hit_xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(c->rc_age.ptr, age, n * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    // the border of the padded grid is not touched by the pass: it goes up and comes back as the caller has it
+    HIP_TRY(c, hipMemcpyAsync(c->rc_pel.ptr, pixel_element, cells * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->rc_pdep.ptr, pixel_depth, cells * sizeof(double), hipMemcpyHostToDevice, s));
+    PTR_TRY(rc_enqueue(c, cam, n_items, static_cast<const double*>(c->rc_hit.ptr), static_cast<double*>(c->rc_age.ptr),
+                       age_factor, depth_threshold, static_cast<int32_t*>(c->rc_item.ptr),
+                       static_cast<int32_t*>(c->rc_pel.ptr), static_cast<double*>(c->rc_pdep.ptr), s));
+    if (n) {
+        HIP_TRY(c, hipMemcpyAsync(age, c->rc_age.ptr, n * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(item_pixel, c->rc_item.ptr, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(c, hipMemcpyAsync(pixel_element, c->rc_pel.ptr, cells * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(pixel_depth, c->rc_pdep.ptr, cells * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
     return PTR_OK;
 }
 

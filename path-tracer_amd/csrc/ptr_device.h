@@ -152,6 +152,21 @@ struct TraceArgs {
     double* out_normal;              // nullable
 };
 
+// render cache reprojection pass (ptr_kernels_rc.hip); all pointers are device memory
+struct RcArgs {
+    double from[3], view[16], proj[16];      // camera.from, matrixWorldInverse, projectionMatrix (column-major)
+    int32_t width, height, n_items;
+    double age_factor, depth_threshold;
+    const double* hit_xyz;                   // 3 per item, NaN in x = no hit
+    double* age;                             // in/out
+    int32_t* item_pixel;                     // out: pixel (y * (width + 2) + x) the item was attached to, or -1
+    int32_t* pixel_element;                  // out, (width + 2) * (height + 2), interior only
+    double* pixel_depth;                     // out, same grid
+    // scratch owned by the context
+    double* item_depth;
+    uint32_t *sort_key, *sort_val, *sorted_key, *sorted_val;
+};
+
 // image row of local row `row` (band: start_y + row; cyclic strips: strip k belongs to part k % n_parts)
 __host__ __device__ inline int global_y(const RenderArgs& a, int row)
 {

@@ -28,7 +28,7 @@ SYMBOLS = [
     "ptr_set_scene", "ptr_set_scene_f64", "ptr_set_scene_sequence_f64",
     "ptr_set_background", "ptr_set_background_f64", "ptr_set_camera",
     "ptr_render", "ptr_render_device", "ptr_render_strips_device", "ptr_strip_rows", "ptr_sync",
-    "ptr_trace_batch", "ptr_trace_batch_f64", "ptr_trace_samples_f64", "ptr_get_stats", "ptr_get_kernel_ms",
+    "ptr_trace_batch", "ptr_trace_batch_f64", "ptr_trace_samples_f64", "ptr_rc_reproject", "ptr_rc_reproject_device", "ptr_get_stats", "ptr_get_kernel_ms",
 ]
 
 
@@ -41,6 +41,11 @@ class Params(C.Structure):
 class Camera(C.Structure):
     _fields_ = [("origin", C.c_double * 3), ("right", C.c_double * 3), ("up", C.c_double * 3),
                 ("forward", C.c_double * 3), ("tan_half_fov", C.c_double)]
+
+
+class RcCamera(C.Structure):
+    _fields_ = [("from_", C.c_double * 3), ("view", C.c_double * 16), ("proj", C.c_double * 16),
+                ("width", C.c_int32), ("height", C.c_int32)]
 
 
 class Strips(C.Structure):
@@ -120,6 +125,9 @@ def lib():
         L.ptr_trace_batch.argtypes = [vp, fp, C.c_int, C.POINTER(C.c_uint8), fp, fp]
         L.ptr_trace_batch_f64.argtypes = [vp, dp, dp, C.c_int, dp, C.POINTER(C.c_int32), dp, dp]
         L.ptr_trace_samples_f64.argtypes = [vp, dp, dp, C.c_int, dp, C.POINTER(C.c_uint8), dp, dp]
+        ip = C.POINTER(C.c_int32)
+        L.ptr_rc_reproject.argtypes = [vp, C.POINTER(RcCamera), C.c_int, dp, dp, C.c_double, C.c_double, ip, ip, dp]
+        L.ptr_rc_reproject_device.argtypes = [vp, C.POINTER(RcCamera), C.c_int, vp, vp, C.c_double, C.c_double, vp, vp, vp, vp]
         L.ptr_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.ptr_get_kernel_ms.argtypes = [vp, fp, fp]
         _lib = L
@@ -259,6 +267,35 @@ class Renderer:
         self._check(self._L.ptr_trace_samples_f64(self._h, _dp(origin), _dp(dirs), n, _dp(rgb),
                                                   rgb8.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(hit), _dp(nrm)))
         return rgb, rgb8, hit, nrm
+
+    @staticmethod
+    def rc_camera(cam_from, view, proj, width, height):
+        cam = RcCamera()
+        cam.from_[:] = [float(v) for v in cam_from]
+        cam.view[:] = [float(v) for v in view]
+        cam.proj[:] = [float(v) for v in proj]
+        cam.width, cam.height = width, height
+        return cam
+
+    def rc_reproject(self, cam_from, view, proj, width, height, hits, age, age_factor=1.0, depth_threshold=1e6):
+        """render cache reprojection pass on host arrays; returns (age_out, item_pixel, pixel_element, pixel_depth)
+        with the never-written grid border holding -2 / NaN"""
+        cam = self.rc_camera(cam_from, view, proj, width, height)
+        hits = np.ascontiguousarray(hits, dtype=np.float64).reshape(-1, 3)
+        n = hits.shape[0]
+        age = np.array(age, dtype=np.float64, copy=True)
+        item_pixel = np.empty(n, dtype=np.int32)
+        cells = (width + 2) * (height + 2)
+        el = np.full(cells, -2, dtype=np.int32); dep = np.full(cells, np.nan)
+        ip = C.POINTER(C.c_int32)
+        self._check(self._L.ptr_rc_reproject(self._h, C.byref(cam), n, _dp(hits), _dp(age), age_factor, depth_threshold,
+                                             item_pixel.ctypes.data_as(ip), el.ctypes.data_as(ip), _dp(dep)))
+        return age, item_pixel, el, dep
+
+    def rc_reproject_device(self, cam, n, d_hit, d_age, d_item_pixel, d_pel, d_pdep, age_factor=1.0, depth_threshold=1e6, stream=None):
+        self._check(self._L.ptr_rc_reproject_device(self._h, C.byref(cam), n, C.c_void_p(d_hit), C.c_void_p(d_age), age_factor,
+                                                    depth_threshold, C.c_void_p(d_item_pixel), C.c_void_p(d_pel),
+                                                    C.c_void_p(d_pdep), C.c_void_p(stream) if stream else None))
 
     def trace_batch(self, dirs, want_hit=False):
         dirs = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
