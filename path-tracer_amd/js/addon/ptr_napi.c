@@ -409,6 +409,53 @@ static napi_value js_trace_samples(napi_env env, napi_callback_info info)
     return out;
 }
 
+/* rcReproject(h, Float64Array camera(35: from[3] view[16] proj[16]), width, height, Float64Array hits(3n, NaN x = no hit),
+ *             Float64Array age(n, updated in place), ageFactor, depthThreshold)
+ *   -> {itemPixel: Int32Array(n), pixelElement: Int32Array((w+2)(h+2)), pixelDepth: Float64Array((w+2)(h+2))}
+ * Driver.reprojectFrame of the render cache (ptr_rc_reproject); the grid border keeps -1 / depthThreshold. */
+static napi_value js_rc_reproject(napi_env env, napi_callback_info info)
+{
+    napi_value argv[8];
+    if (!get_args(env, info, 8, argv)) return NULL;
+    ptr_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    double *cam, *hits, *age; size_t nc, nh, na;
+    int32_t w, h;
+    double age_factor, depth_threshold;
+    if (!get_f64_array(env, argv[1], &cam, &nc) || !get_i32(env, argv[2], &w) || !get_i32(env, argv[3], &h) ||
+        !get_f64_array(env, argv[4], &hits, &nh) || !get_f64_array(env, argv[5], &age, &na)) return NULL;
+    if (napi_get_value_double(env, argv[6], &age_factor) != napi_ok || napi_get_value_double(env, argv[7], &depth_threshold) != napi_ok) {
+        napi_throw_type_error(env, NULL, "ageFactor and depthThreshold must be numbers");
+        return NULL;
+    }
+    if (!cam || nc != 35 || w < 1 || h < 1 || (uint64_t)(w + 2) * (uint64_t)(h + 2) > 0x3fffffffull || nh != 3 * na || na > 0x3fffffff) {
+        napi_throw_range_error(env, "PTR_ERR_INVALID", "camera needs 35 numbers, hits 3 per item, age 1 per item");
+        return NULL;
+    }
+    ptr_rc_camera c;
+    memcpy(c.from, cam, 3 * sizeof(double));
+    memcpy(c.view, cam + 3, 16 * sizeof(double));
+    memcpy(c.proj, cam + 19, 16 * sizeof(double));
+    c.width = w; c.height = h;
+    size_t cells = (size_t)(w + 2) * (size_t)(h + 2);
+    napi_value ab_i, ab_e, ab_d, ti, te, td, out;
+    void *d_i, *d_e, *d_d;
+    NAPI_TRY(env, napi_create_arraybuffer(env, (na ? na : 1) * sizeof(int32_t), &d_i, &ab_i));
+    NAPI_TRY(env, napi_create_arraybuffer(env, cells * sizeof(int32_t), &d_e, &ab_e));
+    NAPI_TRY(env, napi_create_arraybuffer(env, cells * sizeof(double), &d_d, &ab_d));
+    for (size_t k = 0; k < cells; k++) { ((int32_t *)d_e)[k] = -1; ((double *)d_d)[k] = depth_threshold; }
+    int rc = ptr_rc_reproject(ctx, &c, (int)na, hits, age, age_factor, depth_threshold, (int32_t *)d_i, (int32_t *)d_e, (double *)d_d);
+    if (rc != PTR_OK) return throw_ptr(env, ctx, rc);
+    NAPI_TRY(env, napi_create_typedarray(env, napi_int32_array, na, ab_i, 0, &ti));
+    NAPI_TRY(env, napi_create_typedarray(env, napi_int32_array, cells, ab_e, 0, &te));
+    NAPI_TRY(env, napi_create_typedarray(env, napi_float64_array, cells, ab_d, 0, &td));
+    NAPI_TRY(env, napi_create_object(env, &out));
+    NAPI_TRY(env, napi_set_named_property(env, out, "itemPixel", ti));
+    NAPI_TRY(env, napi_set_named_property(env, out, "pixelElement", te));
+    NAPI_TRY(env, napi_set_named_property(env, out, "pixelDepth", td));
+    return out;
+}
+
 static napi_value js_stats(napi_env env, napi_callback_info info)
 {
     napi_value argv[1];
@@ -434,7 +481,7 @@ NAPI_MODULE_INIT()
     const struct { const char *name; napi_callback fn; } fns[] = {
         {"create", js_create}, {"destroy", js_destroy}, {"setScene", js_set_scene},
         {"setBackground", js_set_background}, {"setCamera", js_set_camera}, {"render", js_render},
-        {"renderAsync", js_render_async}, {"traceBatch", js_trace_batch}, {"traceSamples", js_trace_samples}, {"stats", js_stats},
+        {"renderAsync", js_render_async}, {"traceBatch", js_trace_batch}, {"traceSamples", js_trace_samples}, {"rcReproject", js_rc_reproject}, {"stats", js_stats},
     };
     for (size_t k = 0; k < sizeof fns / sizeof fns[0]; k++) {
         napi_value f;

@@ -6,7 +6,7 @@ import fs from 'fs';
 import path from 'path';
 import { fileURLToPath } from 'url';
 import assert from 'assert';
-import { Vector3, Material, Sphere, Scene, Color, Camera, RayTracer, RenderPlanner } from '../index.js';
+import { Vector3, Material, Sphere, Scene, Color, Camera, RayTracer, RenderPlanner, RenderCache } from '../index.js';
 
 const here = path.dirname(fileURLToPath(import.meta.url));
 const golden = path.join(here, '..', '..', '..', 'tests', 'golden');
@@ -224,6 +224,42 @@ async function gpuTests() {
             }
             rt.dispose();
         }
+    });
+    test('RenderCache.reprojectDriver(): Driver.reprojectFrame of the render cache, bit for bit (rendercache-js goldens)', () => {
+        const idx = JSON.parse(fs.readFileSync(path.join(golden, 'rc', 'reproject_index.json')));
+        const rc = new RenderCache();
+        for (const [name, m] of Object.entries(idx.cases)) {
+            const rec = f64(path.join('rc', m.file));
+            const w = m.width, h = m.height, n = m.items, stride = w + 2, cells = stride * (h + 2);
+            // a Driver-shaped object built from the recorded inputs (same field names as the reference's)
+            const buffer = [], addressY = [];
+            for (let y = 0; y <= h + 1; y++) { addressY[y] = y * stride; for (let x = 0; x <= w + 1; x++) buffer.push({ x, y, element: null, depth: 1e13, sample: true }); }
+            const cache = [];
+            for (let i = 0; i < n; i++) {
+                const o = 35 + 4 * i;
+                cache.push({ hit: Number.isNaN(rec[o]) ? null : { x: rec[o], y: rec[o + 1], z: rec[o + 2] }, age: rec[o + 3], pixel: buffer[0] });
+            }
+            const driver = { cache, cacheSize: n, ageFactor: m.age_factor, depthThreshold: m.depth_threshold, buffer, addressY,
+                             getPixel(x, y) { return this.buffer[this.addressY[y] + x]; },
+                             camera: { from: { x: rec[0], y: rec[1], z: rec[2] }, scope: { x: w, y: h },
+                                       cam: { matrixWorldInverse: { elements: Array.from(rec.subarray(3, 19)) },
+                                              projectionMatrix: { elements: Array.from(rec.subarray(19, 35)) } } } };
+            rc.reprojectDriver(driver);
+            const o1 = 35 + 4 * n, o2 = o1 + 2 * n;
+            for (let i = 0; i < n; i++) {
+                assert.strictEqual(cache[i].age, rec[o1 + 2 * i], `${name} age ${i}`);
+                const p = cache[i].pixel;
+                assert.strictEqual(p ? p.y * stride + p.x : -1, rec[o1 + 2 * i + 1], `${name} pixel ${i}`);
+            }
+            for (let y = 1; y <= h; y++) for (let x = 1; x <= w; x++) {
+                const px = driver.getPixel(x, y), c = y * stride + x;
+                assert.strictEqual(px.element ? cache.indexOf(px.element) : -1, rec[o2 + 2 * c], `${name} element ${x},${y}`);
+                assert.strictEqual(px.depth, rec[o2 + 2 * c + 1]);
+                assert.strictEqual(px.sample, false);
+            }
+            assert.strictEqual(cells, (rec.length - o2) / 2);
+        }
+        rc.dispose();
     });
     test('argument validation', () => {
         const rt = new RayTracer(new Vector3(2, 2, 2), buildExample1());
