@@ -264,6 +264,42 @@ int ptr_rc_reproject_device(ptr_ctx *ctx, const ptr_rc_camera *camera, int n_ite
                             double age_factor, double depth_threshold, void *d_item_pixel, void *d_pixel_element,
                             void *d_pixel_depth, void *stream);
 
+/* ---- render cache: depth culling, gap filling, frames ----------------------------------- */
+
+typedef struct ptr_rc_shade_params {
+    int32_t width, height;          /* camera.scope                                                         */
+    double  age_factor;             /* Driver.ageFactor (1)                                                 */
+    double  interpolation_zero;     /* Driver.interpolationZero (20)                                        */
+    double  interpolation_random;   /* Driver.interpolationRandom (5)                                       */
+    double  priority_max;           /* Driver.priorityMax (255)                                             */
+} ptr_rc_shade_params;
+
+/* Replaces Driver.depthCulling() (rendercache-js/src/Driver.js:488-554), Driver.fillGaps() (:556-679) and the frame
+ * getters getColorFrame / getReprojectionFrame / getPriorityFrame (:960-1018), on the state ptr_rc_reproject leaves:
+ *   pixel_element / pixel_depth   in, padded grid (width + 2) * (height + 2)
+ *   item_age        in/out: + 10 age factors where a pixel's depth differs by more than 10 % from the mean depth of
+ *                   its diagonal neighbours (:536)
+ *   item_rgb        in: cacheItem.color as bytes, r | g << 8 | b << 16 (what Sample.doRaytracing leaves)
+ *   pixel_rgb       out, grid: pixel.color in the same packing (the element's colour, or the weighted mean of the
+ *                   neighbours that have one, corner 1 / edge 2, floored; 0 when none has)
+ *   pixel_priority  out, grid: pixel.priority (age >> 1 / round(mean age + zero - items * random) / priority_max);
+ *                   pixel.weight is 0 for every pixel in the reference (:236), so that term is 0 here too
+ *   hist            out: 3 x 256 bins, priorities[INTERPOLATED], [URGENT], [SAMPLED]; priorities outside 0..255 are
+ *                   not counted (the reference's arrays hold NaN properties for those)
+ *   stats           out: statistics.completeness, statistics.totalPriority, increment of this.totalPriority
+ *   *_frame         out, nullable, width * height RGBA8 words each, rows bottom-up as the reference stores them
+ * Only the grid's interior is written.  Preconditions: ages are finite integers, colours are bytes.
+ * ptr_rc_shade: HOST pointers, waits.  ptr_rc_shade_device: DEVICE pointers, enqueues on `stream`; d_hist = 768
+ * uint32, d_totals = 3 int64 (pixels with an element, totalPriority, this.totalPriority increment).            */
+int ptr_rc_shade(ptr_ctx *ctx, const ptr_rc_shade_params *params, int n_items, const int32_t *pixel_element,
+                 const double *pixel_depth, double *item_age, const uint32_t *item_rgb, uint32_t *pixel_rgb,
+                 int32_t *pixel_priority, uint32_t *hist, double stats[3], uint32_t *color_frame,
+                 uint32_t *reprojection_frame, uint32_t *priority_frame);
+int ptr_rc_shade_device(ptr_ctx *ctx, const ptr_rc_shade_params *params, int n_items, const void *d_pixel_element,
+                        const void *d_pixel_depth, void *d_item_age, const void *d_item_rgb, void *d_pixel_rgb,
+                        void *d_pixel_priority, void *d_hist, void *d_totals, void *d_color_frame,
+                        void *d_reprojection_frame, void *d_priority_frame, void *stream);
+
 /* ---- introspection ----------------------------------------------------------------------- */
 int ptr_get_stats(ptr_ctx *ctx, ptr_stats *out);
 

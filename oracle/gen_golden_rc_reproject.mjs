@@ -43,6 +43,9 @@ async function main() {
         const indexPath = path.join(outDir, 'reproject_index.json');
         const index = { generator: 'oracle/gen_golden_rc_reproject.mjs', node: process.version, three: global.THREE.REVISION,
                         reference: 'rendercache-js/src Driver.reprojectFrame + Camera.reprojectPixel (unmodified), three.js as vendored',
+                        shade_layout: 'float64: per item colour r g b (NaN = none) | per item age after depthCulling | per pixel of the (w+2)x(h+2) grid: ' +
+                                      'colour r g b, priority | 3 x 256 histogram bins (INTERPOLATED, URGENT, SAMPLED) | completeness, statistics.totalPriority, ' +
+                                      'this.totalPriority;  .u32: getColorFrame, getReprojectionFrame, getPriorityFrame (w*h each)',
                         layout: 'float64: from[3] view[16] proj[16] | per item: hx hy hz (NaN = no hit) age_in | per item: age_out item_pixel | ' +
                                 'per pixel of the (w+2)x(h+2) grid: element depth', cases: {} };
         const cases = [
@@ -67,13 +70,16 @@ async function main() {
                 item.age = Math.floor(rng() * 30);
                 if (rng() < 0.7) {
                     item.rayDir = camera.computeDirToXY(1 + rng() * (cs.w - 1), 1 + rng() * (cs.h - 1));
-                    tracer.trace(camera.from, item, 0);       // sets item.hit / item.normalDir
+                    item.pixel = { color: null };             // doRaytracing stores the colour there too
+                    item.doRaytracing(tracer, camera.from, item);   // sets item.hit / item.normalDir / item.color
                 }
             }
             // special hits: exactly at the new eye (depth 0), behind the new camera, duplicates (equal depths)
-            drv.cache[3].hit = new Vector3(...cs.fromB);
-            drv.cache[5].hit = new Vector3(cs.fromB[0], cs.fromB[1], cs.fromB[2] + 50);
-            if (drv.cache[7].hit) for (const j of [9, 11, 400]) drv.cache[j].hit = drv.cache[7].hit.clone();
+            const Color = (await import(pathToFileURL(path.join(tmp, 'src', 'Color.js')).href)).default;
+            const grey = () => { const c = new Color(); c.copy(128, 64, 32); return c; };
+            drv.cache[3].hit = new Vector3(...cs.fromB); drv.cache[3].color = grey();
+            drv.cache[5].hit = new Vector3(cs.fromB[0], cs.fromB[1], cs.fromB[2] + 50); drv.cache[5].color = grey();
+            if (drv.cache[7].hit) for (const j of [9, 11, 400]) { drv.cache[j].hit = drv.cache[7].hit.clone(); drv.cache[j].color = grey(); }
             // camera B: the state three.js is in when reprojectFrame runs is what gets recorded
             camera.updatePosition(new Vector3(...cs.fromB), new Vector3(...cs.toB));
             camera.cam.updateMatrixWorld();
@@ -94,9 +100,32 @@ async function main() {
                 const p = drv.getPixel(x, y);
                 rec.push(p.element ? p.element._i : -1, p.depth);
             }
+            // ---- rank 3: depth culling + gap filling + the three frames, on the state reprojectFrame left
+            const rec3 = [];
+            for (let i = 0; i < n; i++) { const c = drv.cache[i].color; rec3.push(c ? c.r : NaN, c ? c.g : NaN, c ? c.b : NaN); }
+            drv.totalPriority = 0;
+            drv.depthCulling();
+            drv.fillGaps();
+            for (let i = 0; i < n; i++) rec3.push(drv.cache[i].age);
+            for (let y = 0; y <= cs.h + 1; y++) for (let x = 0; x <= cs.w + 1; x++) {
+                const p = drv.getPixel(x, y);
+                rec3.push(p.color.r, p.color.g, p.color.b, p.priority);
+            }
+            for (let k = 0; k < 3; k++) for (let j = 0; j < 256; j++) rec3.push(drv.priorities[k][j]);
+            rec3.push(drv.statistics.completeness, drv.statistics.totalPriority, drv.totalPriority);
+            const frames = new Uint32Array(3 * cs.w * cs.h);
+            drv.getColorFrame(frames.subarray(0, cs.w * cs.h));
+            drv.getReprojectionFrame(frames.subarray(cs.w * cs.h, 2 * cs.w * cs.h));
+            drv.getPriorityFrame(frames.subarray(2 * cs.w * cs.h));
+            fs.writeFileSync(path.join(outDir, `shade_${cs.name}.f64`), Buffer.from(new Float64Array(rec3).buffer));
+            fs.writeFileSync(path.join(outDir, `shade_${cs.name}.u32`), Buffer.from(frames.buffer));
+            const oob = [0, 1, 2].map(k => Object.keys(drv.priorities[k]).filter(j => !(Number(j) >= 0 && Number(j) < 256)).length);
+            console.log(cs.name, 'histogram keys outside 0..255:', oob, 'completeness', drv.statistics.completeness);
             const fn = `reproject_${cs.name}.f64`;
             fs.writeFileSync(path.join(outDir, fn), Buffer.from(new Float64Array(rec).buffer));
-            index.cases[cs.name] = { file: fn, width: cs.w, height: cs.h, items: n, age_factor: drv.ageFactor, depth_threshold: drv.depthThreshold };
+            index.cases[cs.name] = { file: fn, width: cs.w, height: cs.h, items: n, age_factor: drv.ageFactor, depth_threshold: drv.depthThreshold,
+                                     shade: `shade_${cs.name}.f64`, shade_frames: `shade_${cs.name}.u32`,
+                                     interpolation_zero: drv.interpolationZero, interpolation_random: drv.interpolationRandom, priority_max: drv.priorityMax };
             const attached = drv.cache.filter(it => it.pixel).length;
             console.log(cs.name, 'items', n, 'with pixel', attached);
         }

@@ -72,6 +72,10 @@ def lib():
         ip = C.POINTER(C.c_int32)
         L.orc_rc_reproject_frame.argtypes = [dp, dp, dp, C.c_int, C.c_int, C.c_int, dp, dp, C.c_double, C.c_double, ip, ip, dp]
         L.orc_rc_reproject_frame.restype = None
+        up = C.POINTER(C.c_uint32)
+        L.orc_rc_shade_frame.argtypes = [C.c_int, C.c_int, C.c_int, ip, dp, dp, dp, C.c_double, C.c_double, C.c_double, C.c_double,
+                                         dp, dp, dp, dp, up, up, up]
+        L.orc_rc_shade_frame.restype = None
         L.orc_pack.argtypes = [dp]
         L.orc_pack.restype = C.c_uint32
         L.orc_reference_angle.restype = C.c_double
@@ -257,3 +261,18 @@ def rc_reproject(cam_from, view, proj, width, height, hits, age, age_factor=1.0,
     lib().orc_rc_reproject_frame(_dp(cam_from), _dp(view), _dp(proj), width, height, n, _dp(hits), _dp(age), age_factor,
                                  depth_threshold, item_pixel.ctypes.data_as(ip), el.ctypes.data_as(ip), _dp(dep))
     return age, item_pixel, el, dep
+
+
+def rc_shade(width, height, pixel_element, pixel_depth, item_age, item_rgb, age_factor=1.0, zero=20.0, rnd=5.0, pmax=255.0):
+    """depth culling + gap filling + frames; returns dict(age, pixel_rgb, pixel_priority, hist, stats, color, reprojection, priority)"""
+    n = len(item_age)
+    el = np.ascontiguousarray(pixel_element, dtype=np.int32); dep = np.ascontiguousarray(pixel_depth, dtype=np.float64)
+    age = np.array(item_age, dtype=np.float64, copy=True); rgb = np.ascontiguousarray(item_rgb, dtype=np.float64).reshape(-1, 3)
+    cells = (width + 2) * (height + 2)
+    prgb = np.zeros((cells, 3)); pprio = np.zeros(cells); hist = np.zeros(3 * 256); stats = np.zeros(3)
+    frames = [np.zeros(width * height, dtype=np.uint32) for _ in range(3)]
+    ip = C.POINTER(C.c_int32); up = C.POINTER(C.c_uint32)
+    lib().orc_rc_shade_frame(width, height, n, el.ctypes.data_as(ip), _dp(dep), _dp(age), _dp(rgb), age_factor, zero, rnd, pmax,
+                             _dp(prgb), _dp(pprio), _dp(hist), _dp(stats), *[f.ctypes.data_as(up) for f in frames])
+    return dict(age=age, pixel_rgb=prgb, pixel_priority=pprio, hist=hist.reshape(3, 256), stats=stats,
+                color=frames[0], reprojection=frames[1], priority=frames[2])

@@ -553,3 +553,99 @@ void orc_rc_reproject_frame(const double from[3], const double view[16], const d
         }
     }
 }
+
+
+/* ======================= rendercache-js: depth culling, gap filling, frames ===========
+ * Driver.depthCulling (RC/src/Driver.js:488-554), Driver.fillGaps (:556-679), getColorFrame / getReprojectionFrame /
+ * getPriorityFrame (:960-1018), on the state reprojectFrame leaves.  pixel.weight is 0 for every pixel in the
+ * reference (Driver.allocBuffers sets this.weight on the Driver, :236), so the neighbourhood weight is 0. */
+void orc_rc_shade_frame(int width, int height, int n_items, const int32_t *pixel_element, const double *pixel_depth,
+                        double *item_age, const double *item_rgb, double age_factor,
+                        double interpolation_zero, double interpolation_random, double priority_max,
+                        double *pixel_rgb, double *pixel_priority, double *hist /* 3 x 256 */, double stats[3],
+                        uint32_t *color_frame, uint32_t *reprojection_frame, uint32_t *priority_frame)
+{
+    const int stride = width + 2;
+    (void)n_items;
+    /* depthCulling */
+    for (int y = 1; y <= height; y++)
+        for (int x = 1; x <= width; x++) {
+            const int p = y * stride + x, e = pixel_element[p];
+            if (e >= 0) {
+                double items = 0, sum = 0;
+                for (int i = -1; i <= 1; i++)
+                    for (int j = -1; j <= 1; j++)
+                        if (i != 0 && j != 0) {
+                            const int q = (y + j) * stride + (x + i);
+                            const int border = (x + i == 0 || x + i == width + 1 || y + j == 0 || y + j == height + 1);
+                            if (!border && pixel_element[q] >= 0) { sum += pixel_depth[q]; items++; }
+                        }
+                if (items != 0) {
+                    const double ratio = sum / (items * pixel_depth[p]);
+                    if (ratio < 0.9 || ratio > 1.1) item_age[e] += (age_factor * 10);
+                }
+                pixel_rgb[3 * p] = item_rgb[3 * e]; pixel_rgb[3 * p + 1] = item_rgb[3 * e + 1]; pixel_rgb[3 * p + 2] = item_rgb[3 * e + 2];
+            } else {
+                pixel_rgb[3 * p] = pixel_rgb[3 * p + 1] = pixel_rgb[3 * p + 2] = 0;
+            }
+        }
+    /* fillGaps */
+    for (int k = 0; k < 3 * 256; k++) hist[k] = 0;
+    double total = 0, member_total = 0, completeness = 0;
+    for (int y = 1; y <= height; y++)
+        for (int x = 1; x <= width; x++) {
+            const int p = y * stride + x, e = pixel_element[p];
+            double prio;
+            if (e < 0) {
+                double age = 0, weight = 0, items = 0, cw = 0, r = 0, g = 0, b = 0;
+                for (int i = -1; i <= 1; i++)
+                    for (int j = -1; j <= 1; j++) {
+                        const int q = (y + j) * stride + (x + i);
+                        const int border = (x + i == 0 || x + i == width + 1 || y + j == 0 || y + j == height + 1);
+                        const double iw = (i != 0 && j != 0) ? 1 : 2;
+                        weight += 0;                                             /* pixel.weight */
+                        if (!border && pixel_element[q] >= 0) {
+                            r += pixel_rgb[3 * q] * iw; g += pixel_rgb[3 * q + 1] * iw; b += pixel_rgb[3 * q + 2] * iw;
+                            age += item_age[pixel_element[q]];
+                            cw += iw;
+                            items++;
+                        }
+                    }
+                if (items > 0) {
+                    pixel_rgb[3 * p] = floor(r / cw); pixel_rgb[3 * p + 1] = floor(g / cw); pixel_rgb[3 * p + 2] = floor(b / cw);
+                    prio = age / items;
+                    prio += (interpolation_zero + (weight - items) * interpolation_random);
+                    prio = js_round(prio);
+                    if (prio >= 0 && prio < 256 && prio == floor(prio)) hist[0 * 256 + (int)prio]++;
+                    member_total += prio;
+                } else {
+                    pixel_rgb[3 * p] = pixel_rgb[3 * p + 1] = pixel_rgb[3 * p + 2] = 0;
+                    prio = priority_max;
+                    if (prio >= 0 && prio < 256 && prio == floor(prio)) hist[1 * 256 + (int)prio]++;
+                    total += prio;
+                }
+            } else {
+                prio = (double)(js_to_int32(item_age[e]) >> 1);
+                if (prio > 0) total += prio;
+                if (prio >= 0 && prio < 256) hist[2 * 256 + (int)prio]++;
+                completeness += 1.0;
+            }
+            pixel_priority[p] = prio;
+        }
+    stats[0] = 100.0 * (completeness / ((double)width * (double)height));
+    stats[1] = total;
+    stats[2] = member_total;
+    /* frames: rows bottom-up (:965) */
+    size_t at = 0;
+    for (int y = height - 1; y >= 0; y--)
+        for (int x = 0; x < width; x++, at++) {
+            const int p = (y + 1) * stride + (x + 1), e = pixel_element[p];
+            const uint32_t alpha = 255u << 24;
+            color_frame[at] = alpha | ((uint32_t)js_to_int32(pixel_rgb[3 * p + 2]) << 16) | ((uint32_t)js_to_int32(pixel_rgb[3 * p + 1]) << 8)
+                              | (uint32_t)js_to_int32(pixel_rgb[3 * p]);
+            reprojection_frame[at] = e >= 0 ? (alpha | ((uint32_t)js_to_int32(item_rgb[3 * e + 2]) << 16) | ((uint32_t)js_to_int32(item_rgb[3 * e + 1]) << 8)
+                                               | (uint32_t)js_to_int32(item_rgb[3 * e])) : alpha;
+            const uint32_t pr = (uint32_t)js_to_int32(pixel_priority[p]);
+            priority_frame[at] = alpha | (pr << 16) | (pr << 8) | pr;
+        }
+}

@@ -66,6 +66,8 @@ struct ptr_ctx {
     DeviceBuffer tr_in_o, tr_in_d, tr_rgb, tr_el, tr_hit, tr_nrm;   // staging for ptr_trace_batch*
     DeviceBuffer rc_depth, rc_keys, rc_temp;                         // scratch of ptr_rc_reproject*
     DeviceBuffer rc_hit, rc_age, rc_item, rc_pel, rc_pdep;           // staging for ptr_rc_reproject (host buffers)
+    DeviceBuffer rc_rgb, rc_prgb, rc_pprio, rc_hist, rc_frames;      // staging for ptr_rc_shade (host buffers)
+    DeviceBuffer rc_page;                                            // scratch of ptr_rc_shade*: per-pixel element age
     std::vector<unsigned char> host_blocks;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // PTR_FLAG_TIMING
     int timed_kernels = 0;             // kernels bracketed by ev[] in the last timed call
@@ -756,6 +758,109 @@ int rc_enqueue(ptr_ctx* c, const ptr_rc_camera* cam, int n_items, const double* 
     return PTR_OK;
 }
 }  // namespace
+
+namespace {
+int rc_shade_check(ptr_ctx* c, const ptr_rc_shade_params* p, int n_items, const void* pel, const void* pdep, const void* age,
+                   const void* rgb, const void* prgb, const void* pprio, const void* hist, const void* totals)
+{
+    if (!p) return fail(c, PTR_ERR_INVALID, "params is NULL");
+    if (p->width < 1 || p->height < 1 || (long long)(p->width + 2) * (p->height + 2) >= (1ll << 31))
+        return fail(c, PTR_ERR_INVALID, "bad frame size %d x %d", p->width, p->height);
+    if (n_items < 0) return fail(c, PTR_ERR_INVALID, "n_items < 0");
+    if (!pel || !pdep || !prgb || !pprio || !hist || !totals || (n_items > 0 && (!age || !rgb)))
+        return fail(c, PTR_ERR_INVALID, "a required buffer is NULL");
+    return PTR_OK;
+}
+
+RcShadeArgs rc_shade_args(const ptr_rc_shade_params* p, int n_items)
+{
+    RcShadeArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.width = p->width; a.height = p->height; a.n_items = n_items;
+    a.age_factor = p->age_factor; a.interpolation_zero = p->interpolation_zero;
+    a.interpolation_random = p->interpolation_random; a.priority_max = p->priority_max;
+    return a;
+}
+}  // namespace
+
+int ptr_rc_shade_device(ptr_ctx* c, const ptr_rc_shade_params* p, int n_items, const void* d_pixel_element,
+                        const void* d_pixel_depth, void* d_item_age, const void* d_item_rgb, void* d_pixel_rgb,
+                        void* d_pixel_priority, void* d_hist, void* d_totals, void* d_color_frame,
+                        void* d_reprojection_frame, void* d_priority_frame, void* stream)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    PTR_TRY(rc_shade_check(c, p, n_items, d_pixel_element, d_pixel_depth, d_item_age, d_item_rgb, d_pixel_rgb, d_pixel_priority,
+                           d_hist, d_totals));
+    HIP_TRY(c, hipSetDevice(c->device));
+    RcShadeArgs a = rc_shade_args(p, n_items);
+    a.pixel_element = static_cast<const int32_t*>(d_pixel_element); a.pixel_depth = static_cast<const double*>(d_pixel_depth);
+    a.item_age = static_cast<double*>(d_item_age); a.item_rgb = static_cast<const uint32_t*>(d_item_rgb);
+    a.pixel_rgb = static_cast<uint32_t*>(d_pixel_rgb); a.pixel_priority = static_cast<int32_t*>(d_pixel_priority);
+    a.hist = static_cast<uint32_t*>(d_hist); a.totals = static_cast<long long*>(d_totals);
+    a.color_frame = static_cast<uint32_t*>(d_color_frame); a.reprojection_frame = static_cast<uint32_t*>(d_reprojection_frame);
+    a.priority_frame = static_cast<uint32_t*>(d_priority_frame);
+    PTR_TRY(grow(c, c->rc_page, (size_t)(p->width + 2) * (size_t)(p->height + 2) * sizeof(double)));
+    a.pixel_age = static_cast<double*>(c->rc_page.ptr);
+    HIP_TRY(c, launch_rc_shade(a, stream ? static_cast<hipStream_t>(stream) : c->stream));
+    return PTR_OK;
+}
+
+int ptr_rc_shade(ptr_ctx* c, const ptr_rc_shade_params* p, int n_items, const int32_t* pixel_element, const double* pixel_depth,
+                 double* item_age, const uint32_t* item_rgb, uint32_t* pixel_rgb, int32_t* pixel_priority, uint32_t* hist,
+                 double stats[3], uint32_t* color_frame, uint32_t* reprojection_frame, uint32_t* priority_frame)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    PTR_TRY(rc_shade_check(c, p, n_items, pixel_element, pixel_depth, item_age, item_rgb, pixel_rgb, pixel_priority, hist, stats));
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = (size_t)n_items, cells = (size_t)(p->width + 2) * (size_t)(p->height + 2), px = (size_t)p->width * (size_t)p->height;
+    PTR_TRY(grow(c, c->rc_pel, cells * sizeof(int32_t)));
+    PTR_TRY(grow(c, c->rc_pdep, cells * sizeof(double)));
+    PTR_TRY(grow(c, c->rc_age, (n ? n : 1) * sizeof(double)));
+    PTR_TRY(grow(c, c->rc_rgb, (n ? n : 1) * sizeof(uint32_t)));
+    PTR_TRY(grow(c, c->rc_prgb, cells * sizeof(uint32_t)));
+    PTR_TRY(grow(c, c->rc_pprio, cells * sizeof(int32_t)));
+    PTR_TRY(grow(c, c->rc_hist, 3 * 256 * sizeof(uint32_t) + 3 * sizeof(long long)));
+    PTR_TRY(grow(c, c->rc_frames, 3 * px * sizeof(uint32_t)));
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipMemcpyAsync(c->rc_pel.ptr, pixel_element, cells * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->rc_pdep.ptr, pixel_depth, cells * sizeof(double), hipMemcpyHostToDevice, s));
+    // grid borders are not written by the pass: they go up and come back as the caller has them
+    HIP_TRY(c, hipMemcpyAsync(c->rc_prgb.ptr, pixel_rgb, cells * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->rc_pprio.ptr, pixel_priority, cells * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    if (n) {
+        HIP_TRY(c, hipMemcpyAsync(c->rc_age.ptr, item_age, n * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(c->rc_rgb.ptr, item_rgb, n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    }
+    RcShadeArgs a = rc_shade_args(p, n_items);
+    a.pixel_element = static_cast<const int32_t*>(c->rc_pel.ptr); a.pixel_depth = static_cast<const double*>(c->rc_pdep.ptr);
+    a.item_age = static_cast<double*>(c->rc_age.ptr); a.item_rgb = static_cast<const uint32_t*>(c->rc_rgb.ptr);
+    a.pixel_rgb = static_cast<uint32_t*>(c->rc_prgb.ptr); a.pixel_priority = static_cast<int32_t*>(c->rc_pprio.ptr);
+    a.hist = static_cast<uint32_t*>(c->rc_hist.ptr);
+    a.totals = reinterpret_cast<long long*>(static_cast<unsigned char*>(c->rc_hist.ptr) + 3 * 256 * sizeof(uint32_t));
+    uint32_t* fr = static_cast<uint32_t*>(c->rc_frames.ptr);
+    a.color_frame = color_frame ? fr : nullptr;
+    a.reprojection_frame = reprojection_frame ? fr + px : nullptr;
+    a.priority_frame = priority_frame ? fr + 2 * px : nullptr;
+    PTR_TRY(grow(c, c->rc_page, cells * sizeof(double)));
+    a.pixel_age = static_cast<double*>(c->rc_page.ptr);
+    HIP_TRY(c, launch_rc_shade(a, s));
+    long long totals[3];
+    if (n) HIP_TRY(c, hipMemcpyAsync(item_age, c->rc_age.ptr, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(pixel_rgb, c->rc_prgb.ptr, cells * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(pixel_priority, c->rc_pprio.ptr, cells * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(hist, a.hist, 3 * 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(totals, a.totals, sizeof totals, hipMemcpyDeviceToHost, s));
+    if (color_frame) HIP_TRY(c, hipMemcpyAsync(color_frame, fr, px * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (reprojection_frame) HIP_TRY(c, hipMemcpyAsync(reprojection_frame, fr + px, px * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (priority_frame) HIP_TRY(c, hipMemcpyAsync(priority_frame, fr + 2 * px, px * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    stats[0] = 100.0 * ((double)totals[0] / ((double)p->width * (double)p->height));     // Driver.js:676
+    stats[1] = (double)totals[1];
+    stats[2] = (double)totals[2];
+    return PTR_OK;
+}
 
 int ptr_rc_reproject_device(ptr_ctx* c, const ptr_rc_camera* cam, int n_items, const void* d_hit_xyz, void* d_age,
                             double age_factor, double depth_threshold, void* d_item_pixel, void* d_pixel_element,

@@ -167,6 +167,22 @@ struct RcArgs {
     uint32_t *sort_key, *sort_val, *sorted_key, *sorted_val;
 };
 
+// render cache depth culling + gap filling + frames (ptr_kernels_rc.hip); all pointers are device memory
+struct RcShadeArgs {
+    int32_t width, height, n_items;
+    double age_factor, interpolation_zero, interpolation_random, priority_max;
+    const int32_t* pixel_element;            // (width + 2) * (height + 2)
+    const double* pixel_depth;
+    double* item_age;                        // in/out
+    const uint32_t* item_rgb;                // r | g << 8 | b << 16 per item
+    uint32_t* pixel_rgb;                     // out, grid
+    int32_t* pixel_priority;                 // out, grid
+    uint32_t* hist;                          // out, 3 x 256
+    long long* totals;                       // out: pixels with an element, statistics.totalPriority, this.totalPriority increment
+    uint32_t *color_frame, *reprojection_frame, *priority_frame;   // out, width * height each, nullable
+    double* pixel_age;                       // scratch owned by the context, grid: the element's age after culling
+};
+
 // image row of local row `row` (band: start_y + row; cyclic strips: strip k belongs to part k % n_parts)
 __host__ __device__ inline int global_y(const RenderArgs& a, int row)
 {

@@ -22,6 +22,7 @@ int many_kernel_rows_per_block();
 hipError_t launch_render_ext(const RenderArgs& a, int n_frames, bool f64, bool stats, hipStream_t s);
 
 // render cache reprojection pass (ptr_kernels_rc.hip)
+hipError_t launch_rc_shade(const RcShadeArgs& a, hipStream_t s);
 size_t rc_sort_temp_bytes(int n_items, int width, int height);
 hipError_t launch_rc_reproject(const RcArgs& a, void* sort_temp, size_t sort_temp_bytes, hipStream_t s);
 

@@ -107,6 +107,140 @@ static int rc_key_bits(int width, int height)
     return bits;
 }
 
+// ---- rank 3: depth culling, gap filling, frames (Driver.js:488-679, 960-1018) ---------------------------------
+// Both passes are 3x3 stencils over the padded pixel grid and independent per pixel (a pixel's colour is only read
+// when it has an element, and only written when it has none), so each is one kernel, one pixel per lane.
+// Colours are bytes (what Sample.doRaytracing leaves) packed r | g << 8 | b << 16; priorities are integers.
+__device__ __forceinline__ bool rc_border(const RcShadeArgs& a, int x, int y)
+{
+    return x == 0 || x == a.width + 1 || y == 0 || y == a.height + 1;
+}
+
+// Driver.depthCulling: compare a pixel's depth with the mean depth of its 4 DIAGONAL neighbours that have an element.
+// This is also where the element -> item indirection is paid, once per pixel: the item's (possibly just raised) age
+// and its colour are copied into per-pixel arrays, so that the gap filling below reads its 3x3 neighbourhood from
+// contiguous rows instead of gathering 2 x 9 random cache items per empty pixel.
+__global__ void __launch_bounds__(256) rc_cull_kernel(RcShadeArgs a)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x + 1, y = blockIdx.y + 1;
+    if (x > a.width) return;
+    const int stride = a.width + 2;
+    const int p = y * stride + x, e = a.pixel_element[p];
+    if (e < 0) return;
+    double age = a.item_age[e];
+    double items = 0, sum = 0;
+#pragma unroll
+    for (int i = -1; i <= 1; i += 2)
+#pragma unroll
+        for (int j = -1; j <= 1; j += 2) {
+            const int q = (y + j) * stride + (x + i);
+            if (!rc_border(a, x + i, y + j) && a.pixel_element[q] >= 0) { sum += a.pixel_depth[q]; items++; }
+        }
+    if (items != 0) {
+        const double ratio = sum / (items * a.pixel_depth[p]);
+        if (ratio < 0.9 || ratio > 1.1) {                                            // Driver.js:536
+            age += (a.age_factor * 10);
+            a.item_age[e] = age;
+        }
+    }
+    a.pixel_age[p] = age;
+    a.pixel_rgb[p] = a.item_rgb[e];                                                  // pixel.color = cacheItem.color (:547)
+}
+
+// Driver.fillGaps + the three frame getters
+__global__ void __launch_bounds__(256) rc_fill_kernel(RcShadeArgs a)
+{
+    __shared__ unsigned lh[3 * 256];
+    __shared__ long long ltot[3];
+    for (int k = threadIdx.x; k < 3 * 256; k += blockDim.x) lh[k] = 0u;
+    if (threadIdx.x < 3) ltot[threadIdx.x] = 0;
+    __syncthreads();
+    // A workgroup walks rows y, y + gridDim.y, ...: its histogram and sums go to global memory once, and with at most
+    // 128 workgroups per column of the grid the shared bins see ~1000 atomics each instead of one per 256 pixels
+    // (one address takes ~88 atomics per microsecond: 8640 workgroups cost 100 us there).
+    const int x = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    long long t_elem = 0, t_total = 0, t_member = 0;
+    for (int y = blockIdx.y + 1; y <= a.height; y += gridDim.y)
+    if (x <= a.width) {
+        const int stride = a.width + 2;
+        const int p = y * stride + x, e = a.pixel_element[p];
+        uint32_t colour;
+        long long prio;
+        if (e < 0) {
+            double age = 0, weight = 0, items = 0, cw = 0, r = 0, g = 0, b = 0;
+#pragma unroll
+            for (int i = -1; i <= 1; i++)
+#pragma unroll
+                for (int j = -1; j <= 1; j++) {
+                    const int q = (y + j) * stride + (x + i);
+                    const double iw = (i != 0 && j != 0) ? 1 : 2;                   // corner 1, edge and centre 2
+                    if (!rc_border(a, x + i, y + j) && a.pixel_element[q] >= 0) {
+                        const uint32_t c = a.pixel_rgb[q];
+                        r += (double)(c & 255u) * iw; g += (double)((c >> 8) & 255u) * iw; b += (double)((c >> 16) & 255u) * iw;
+                        age += a.pixel_age[q];
+                        cw += iw;
+                        items++;
+                    }
+                }
+            if (items > 0) {
+                const uint32_t fr = (uint32_t)__builtin_floor(r / cw), fg = (uint32_t)__builtin_floor(g / cw), fb = (uint32_t)__builtin_floor(b / cw);
+                colour = fr | (fg << 8) | (fb << 16);
+                double pr = age / items;
+                pr += (a.interpolation_zero + (weight - items) * a.interpolation_random);   // pixel.weight is 0 everywhere
+                prio = (long long)js_round(pr);
+                if (prio >= 0 && prio < 256) atomicAdd(&lh[prio], 1u);
+                t_member += prio;                                                            // this.totalPriority
+            } else {
+                colour = 0u;
+                prio = (long long)a.priority_max;
+                if (prio >= 0 && prio < 256) atomicAdd(&lh[256 + prio], 1u);
+                t_total += prio;
+            }
+            a.pixel_rgb[p] = colour;            // an empty pixel's colour is never read by a neighbour: no race with the reads above
+        } else {
+            colour = a.pixel_rgb[p];
+            prio = (long long)((int32_t)js_to_uint32(a.pixel_age[p]) >> 1);                   // age >> 1
+            if (prio > 0) t_total += prio;
+            if (prio >= 0 && prio < 256) atomicAdd(&lh[512 + prio], 1u);
+            t_elem += 1;
+        }
+        a.pixel_priority[p] = (int32_t)prio;
+        // frames are stored bottom-up (Driver.js:965): grid row y -> frame row height - y
+        const size_t at = (size_t)(a.height - y) * a.width + (x - 1);
+        const uint32_t alpha = 255u << 24;
+        if (a.color_frame) a.color_frame[at] = alpha | (colour & 0xffffffu);
+        if (a.reprojection_frame) a.reprojection_frame[at] = e >= 0 ? (alpha | (colour & 0xffffffu)) : alpha;
+        if (a.priority_frame) { const uint32_t pr = (uint32_t)(int32_t)prio; a.priority_frame[at] = alpha | (pr << 16) | (pr << 8) | pr; }
+    }
+    // the three sums: wave reduction, then one LDS add per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        t_elem += __shfl_xor(t_elem, off, 64); t_total += __shfl_xor(t_total, off, 64); t_member += __shfl_xor(t_member, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd((unsigned long long*)&ltot[0], (unsigned long long)t_elem);
+        atomicAdd((unsigned long long*)&ltot[1], (unsigned long long)t_total);
+        atomicAdd((unsigned long long*)&ltot[2], (unsigned long long)t_member);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 3 * 256; k += blockDim.x)
+        if (lh[k]) atomicAdd(&a.hist[k], lh[k]);
+    if (threadIdx.x < 3 && ltot[threadIdx.x]) atomicAdd((unsigned long long*)&a.totals[threadIdx.x], (unsigned long long)ltot[threadIdx.x]);
+}
+
+hipError_t launch_rc_shade(const RcShadeArgs& a, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(a.hist, 0, 3 * 256 * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(a.totals, 0, 3 * sizeof(long long), s);
+    if (e != hipSuccess) return e;
+    dim3 grid((a.width + 255) / 256, a.height);
+    hipLaunchKernelGGL(rc_cull_kernel, grid, dim3(256), 0, s, a);
+    dim3 fill_grid(grid.x, a.height < 128 ? a.height : 128);
+    hipLaunchKernelGGL(rc_fill_kernel, fill_grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 size_t rc_sort_temp_bytes(int n_items, int width, int height)
 {
     size_t bytes = 0;

@@ -28,7 +28,7 @@ SYMBOLS = [
     "ptr_set_scene", "ptr_set_scene_f64", "ptr_set_scene_sequence_f64",
     "ptr_set_background", "ptr_set_background_f64", "ptr_set_camera",
     "ptr_render", "ptr_render_device", "ptr_render_strips_device", "ptr_strip_rows", "ptr_sync",
-    "ptr_trace_batch", "ptr_trace_batch_f64", "ptr_trace_samples_f64", "ptr_rc_reproject", "ptr_rc_reproject_device", "ptr_get_stats", "ptr_get_kernel_ms",
+    "ptr_trace_batch", "ptr_trace_batch_f64", "ptr_trace_samples_f64", "ptr_rc_reproject", "ptr_rc_reproject_device", "ptr_rc_shade", "ptr_rc_shade_device", "ptr_get_stats", "ptr_get_kernel_ms",
 ]
 
 
@@ -46,6 +46,11 @@ class Camera(C.Structure):
 class RcCamera(C.Structure):
     _fields_ = [("from_", C.c_double * 3), ("view", C.c_double * 16), ("proj", C.c_double * 16),
                 ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class RcShadeParams(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("age_factor", C.c_double), ("interpolation_zero", C.c_double),
+                ("interpolation_random", C.c_double), ("priority_max", C.c_double)]
 
 
 class Strips(C.Structure):
@@ -128,6 +133,9 @@ def lib():
         ip = C.POINTER(C.c_int32)
         L.ptr_rc_reproject.argtypes = [vp, C.POINTER(RcCamera), C.c_int, dp, dp, C.c_double, C.c_double, ip, ip, dp]
         L.ptr_rc_reproject_device.argtypes = [vp, C.POINTER(RcCamera), C.c_int, vp, vp, C.c_double, C.c_double, vp, vp, vp, vp]
+        up = C.POINTER(C.c_uint32)
+        L.ptr_rc_shade.argtypes = [vp, C.POINTER(RcShadeParams), C.c_int, ip, dp, dp, up, up, ip, up, dp, up, up, up]
+        L.ptr_rc_shade_device.argtypes = [vp, C.POINTER(RcShadeParams), C.c_int] + [vp] * 12
         L.ptr_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.ptr_get_kernel_ms.argtypes = [vp, fp, fp]
         _lib = L
@@ -291,6 +299,25 @@ class Renderer:
         self._check(self._L.ptr_rc_reproject(self._h, C.byref(cam), n, _dp(hits), _dp(age), age_factor, depth_threshold,
                                              item_pixel.ctypes.data_as(ip), el.ctypes.data_as(ip), _dp(dep)))
         return age, item_pixel, el, dep
+
+    def rc_shade(self, width, height, pixel_element, pixel_depth, item_age, item_rgb, age_factor=1.0, zero=20.0, rnd=5.0, pmax=255.0):
+        """depth culling + gap filling + frames on host arrays (item_rgb: (n, 3) byte values); same dictionary keys as the tests' CPU checker"""
+        p = RcShadeParams(width, height, age_factor, zero, rnd, pmax)
+        el = np.ascontiguousarray(pixel_element, dtype=np.int32); dep = np.ascontiguousarray(pixel_depth, dtype=np.float64)
+        age = np.array(item_age, dtype=np.float64, copy=True)
+        c = np.asarray(item_rgb, dtype=np.float64).reshape(-1, 3).astype(np.uint32)
+        rgb = np.ascontiguousarray(c[:, 0] | (c[:, 1] << 8) | (c[:, 2] << 16), dtype=np.uint32)
+        cells = (width + 2) * (height + 2)
+        prgb = np.zeros(cells, dtype=np.uint32); pprio = np.zeros(cells, dtype=np.int32)
+        hist = np.zeros(768, dtype=np.uint32); stats = np.zeros(3)
+        frames = [np.zeros(width * height, dtype=np.uint32) for _ in range(3)]
+        ip = C.POINTER(C.c_int32); up = C.POINTER(C.c_uint32)
+        self._check(self._L.ptr_rc_shade(self._h, C.byref(p), len(age), el.ctypes.data_as(ip), _dp(dep), _dp(age), rgb.ctypes.data_as(up),
+                                         prgb.ctypes.data_as(up), pprio.ctypes.data_as(ip), hist.ctypes.data_as(up), _dp(stats),
+                                         *[f.ctypes.data_as(up) for f in frames]))
+        pixel_rgb = np.stack([prgb & 255, (prgb >> 8) & 255, (prgb >> 16) & 255], axis=1).astype(np.float64)
+        return dict(age=age, pixel_rgb=pixel_rgb, pixel_priority=pprio.astype(np.float64), hist=hist.reshape(3, 256).astype(np.float64),
+                    stats=stats, color=frames[0], reprojection=frames[1], priority=frames[2])
 
     def rc_reproject_device(self, cam, n, d_hit, d_age, d_item_pixel, d_pel, d_pdep, age_factor=1.0, depth_threshold=1e6, stream=None):
         self._check(self._L.ptr_rc_reproject_device(self._h, C.byref(cam), n, C.c_void_p(d_hit), C.c_void_p(d_age), age_factor,

@@ -34,6 +34,28 @@ for _ in range(steps):
     r.rc_reproject_device(cam, n, d_hit.data_ptr(), d_age.data_ptr(), d_item.data_ptr(), d_pel.data_ptr(), d_pdep.data_ptr(), stream=s)
 r.sync()
 ms = (time.perf_counter() - t0) * 1e3 / steps
+# ---- rank 3 on the state the reprojection left: depth culling + gap filling + the three frames
+import ctypes as C
+d_rgb = torch.from_numpy(rng.integers(0, 1 << 24, n).astype(np.uint32).view(np.int32)).cuda()
+d_prgb = torch.zeros(cells, dtype=torch.int32, device="cuda"); d_pprio = torch.zeros(cells, dtype=torch.int32, device="cuda")
+d_hist = torch.zeros(768, dtype=torch.int32, device="cuda"); d_tot = torch.zeros(3, dtype=torch.int64, device="cuda")
+d_frames = torch.zeros(3 * W * H, dtype=torch.int32, device="cuda")
+sp = ptr_amd.RcShadeParams(W, H, 1.0, 20.0, 5.0, 255.0)
+def shade():
+    r._check(r._L.ptr_rc_shade_device(r._h, C.byref(sp), n, d_pel.data_ptr(), d_pdep.data_ptr(), d_age.data_ptr(), d_rgb.data_ptr(),
+                                      d_prgb.data_ptr(), d_pprio.data_ptr(), d_hist.data_ptr(), d_tot.data_ptr(),
+                                      d_frames.data_ptr(), d_frames.data_ptr() + 4 * W * H, d_frames.data_ptr() + 8 * W * H, None))
+for _ in range(3): shade()
+r.sync()
+t0 = time.perf_counter()
+for _ in range(steps): shade()
+r.sync()
+ms2 = (time.perf_counter() - t0) * 1e3 / steps
+alg2 = W * H * (4 + 8 + 8 + 4 + 4 + 4 + 12)      # element, depth, the element's age and colour, colour + priority out, 3 frames
+print(json.dumps({"metric": "render-cache depth culling + gap filling + frames, pixels/s", "value": round(W * H / ms2 / 1e3, 1), "unit": "Mpixels/s",
+                  "ms_per_pass": round(ms2, 4), "frame": f"{W}x{H}", "pixels_with_element": int(d_tot[0].item()),
+                  "roofline": {"bound": "hbm", "achieved": round(alg2 / ms2 / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+                               "frac": round(alg2 / ms2 / 1e6 / 8000.0, 4), "algorithmic_bytes": alg2}}))
 alg = n * (24 + 8 + 8 + 4) + W * H * 12
 print(json.dumps({"metric": "render-cache reprojection, cache items/s", "value": round(n / ms / 1e3, 1), "unit": "Mitems/s",
                   "ms_per_pass": round(ms, 4), "items": n, "frame": f"{W}x{H}", "attached": int((d_item >= 0).sum().item()),
