@@ -456,6 +456,69 @@ static napi_value js_rc_reproject(napi_env env, napi_callback_info info)
     return out;
 }
 
+static int get_typed(napi_env env, napi_value v, napi_typedarray_type want, void **data, size_t *len)
+{
+    bool is_ta = false;
+    napi_typedarray_type tt;
+    if (napi_is_typedarray(env, v, &is_ta) != napi_ok || !is_ta ||
+        napi_get_typedarray_info(env, v, &tt, len, data, NULL, NULL) != napi_ok || tt != want) {
+        napi_throw_type_error(env, NULL, "typed array of the wrong kind");
+        return 0;
+    }
+    return 1;
+}
+
+/* rcShade(h, width, height, Int32Array pixelElement, Float64Array pixelDepth, Float64Array itemAge (updated in place),
+ *         Uint32Array itemRgb (r | g << 8 | b << 16), Float64Array params(4: ageFactor, interpolationZero,
+ *         interpolationRandom, priorityMax))
+ *   -> {pixelRgb: Uint32Array(grid), pixelPriority: Int32Array(grid), hist: Uint32Array(768), stats: Float64Array(3),
+ *       colorFrame, reprojectionFrame, priorityFrame: Uint32Array(w*h)}
+ * Driver.depthCulling + Driver.fillGaps + the frame getters of the render cache (ptr_rc_shade). */
+static napi_value js_rc_shade(napi_env env, napi_callback_info info)
+{
+    napi_value argv[8];
+    if (!get_args(env, info, 8, argv)) return NULL;
+    ptr_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    int32_t w, h;
+    void *pel, *pdep, *age, *rgb; size_t npel, npdep, nage, nrgb;
+    double *par; size_t npar;
+    if (!get_i32(env, argv[1], &w) || !get_i32(env, argv[2], &h) ||
+        !get_typed(env, argv[3], napi_int32_array, &pel, &npel) || !get_typed(env, argv[4], napi_float64_array, &pdep, &npdep) ||
+        !get_typed(env, argv[5], napi_float64_array, &age, &nage) || !get_typed(env, argv[6], napi_uint32_array, &rgb, &nrgb) ||
+        !get_f64_array(env, argv[7], &par, &npar)) return NULL;
+    if (w < 1 || h < 1 || (uint64_t)(w + 2) * (uint64_t)(h + 2) > 0x3fffffffull) {
+        napi_throw_range_error(env, "PTR_ERR_INVALID", "bad frame size");
+        return NULL;
+    }
+    size_t cells = (size_t)(w + 2) * (size_t)(h + 2), px = (size_t)w * (size_t)h;
+    if (npel != cells || npdep != cells || nage != nrgb || nage > 0x3fffffff || !par || npar != 4) {
+        napi_throw_range_error(env, "PTR_ERR_INVALID", "pixel arrays need (w+2)*(h+2) entries, itemAge and itemRgb one per item, params 4 numbers");
+        return NULL;
+    }
+    ptr_rc_shade_params p = { w, h, par[0], par[1], par[2], par[3] };
+    napi_value ab[7], ta[7], out;
+    void *d[7];
+    const size_t bytes[7] = { cells * 4, cells * 4, 768 * 4, 3 * 8, px * 4, px * 4, px * 4 };
+    for (int k = 0; k < 7; k++) {
+        NAPI_TRY(env, napi_create_arraybuffer(env, bytes[k], &d[k], &ab[k]));
+        memset(d[k], 0, bytes[k]);
+    }
+    int rc = ptr_rc_shade(ctx, &p, (int)nage, (const int32_t *)pel, (const double *)pdep, (double *)age, (const uint32_t *)rgb,
+                          (uint32_t *)d[0], (int32_t *)d[1], (uint32_t *)d[2], (double *)d[3], (uint32_t *)d[4], (uint32_t *)d[5], (uint32_t *)d[6]);
+    if (rc != PTR_OK) return throw_ptr(env, ctx, rc);
+    const napi_typedarray_type types[7] = { napi_uint32_array, napi_int32_array, napi_uint32_array, napi_float64_array,
+                                            napi_uint32_array, napi_uint32_array, napi_uint32_array };
+    const size_t counts[7] = { cells, cells, 768, 3, px, px, px };
+    const char *names[7] = { "pixelRgb", "pixelPriority", "hist", "stats", "colorFrame", "reprojectionFrame", "priorityFrame" };
+    NAPI_TRY(env, napi_create_object(env, &out));
+    for (int k = 0; k < 7; k++) {
+        NAPI_TRY(env, napi_create_typedarray(env, types[k], counts[k], ab[k], 0, &ta[k]));
+        NAPI_TRY(env, napi_set_named_property(env, out, names[k], ta[k]));
+    }
+    return out;
+}
+
 static napi_value js_stats(napi_env env, napi_callback_info info)
 {
     napi_value argv[1];
@@ -481,7 +544,7 @@ NAPI_MODULE_INIT()
     const struct { const char *name; napi_callback fn; } fns[] = {
         {"create", js_create}, {"destroy", js_destroy}, {"setScene", js_set_scene},
         {"setBackground", js_set_background}, {"setCamera", js_set_camera}, {"render", js_render},
-        {"renderAsync", js_render_async}, {"traceBatch", js_trace_batch}, {"traceSamples", js_trace_samples}, {"rcReproject", js_rc_reproject}, {"stats", js_stats},
+        {"renderAsync", js_render_async}, {"traceBatch", js_trace_batch}, {"traceSamples", js_trace_samples}, {"rcReproject", js_rc_reproject}, {"rcShade", js_rc_shade}, {"stats", js_stats},
     };
     for (size_t k = 0; k < sizeof fns / sizeof fns[0]; k++) {
         napi_value f;

@@ -261,6 +261,42 @@ async function gpuTests() {
         }
         rc.dispose();
     });
+    test('RenderCache.shadeFrame(): Driver.depthCulling + fillGaps + frames, bit for bit (rendercache-js goldens)', () => {
+        const idx = JSON.parse(fs.readFileSync(path.join(golden, 'rc', 'reproject_index.json')));
+        const rc = new RenderCache();
+        const eq = (x, y, msg) => assert.ok(x === y, `${msg || ''} ${x} !== ${y}`);      // Math.round gives -0 in the reference; an int32 holds 0
+        for (const [name, m] of Object.entries(idx.cases)) {
+            const rp = f64(path.join('rc', m.file)), sh = f64(path.join('rc', m.shade));
+            const fb = fs.readFileSync(path.join(golden, 'rc', m.shade_frames));
+            const frames = new Uint32Array(fb.buffer, fb.byteOffset, fb.length / 4);
+            const w = m.width, h = m.height, n = m.items, stride = w + 2, cells = stride * (h + 2);
+            const o1 = 35 + 4 * n, o2 = o1 + 2 * n;
+            const pel = new Int32Array(cells), pdep = new Float64Array(cells), age = new Float64Array(n), rgb = new Uint32Array(n);
+            for (let c = 0; c < cells; c++) { pel[c] = rp[o2 + 2 * c]; pdep[c] = rp[o2 + 2 * c + 1]; }
+            for (let i = 0; i < n; i++) {
+                age[i] = rp[o1 + 2 * i];
+                if (!Number.isNaN(sh[3 * i])) rgb[i] = sh[3 * i] | (sh[3 * i + 1] << 8) | (sh[3 * i + 2] << 16);
+            }
+            const out = rc.shadeFrame(w, h, pel, pdep, age, rgb, { ageFactor: m.age_factor, interpolationZero: m.interpolation_zero,
+                                      interpolationRandom: m.interpolation_random, priorityMax: m.priority_max });
+            let o = 3 * n;
+            for (let i = 0; i < n; i++) eq(age[i], sh[o + i], `${name} age ${i}`);
+            o += n;
+            for (let y = 1; y <= h; y++) for (let x = 1; x <= w; x++) {
+                const c = y * stride + x, v = out.pixelRgb[c];
+                eq(v & 255, sh[o + 4 * c]); eq((v >> 8) & 255, sh[o + 4 * c + 1]);
+                eq((v >> 16) & 255, sh[o + 4 * c + 2]); eq(out.pixelPriority[c], sh[o + 4 * c + 3]);
+            }
+            o += 4 * cells;
+            for (let k = 0; k < 768; k++) eq(out.hist[k], Number.isNaN(sh[o + k]) ? 0 : sh[o + k]);
+            o += 768;
+            for (let k = 0; k < 3; k++) eq(out.stats[k], sh[o + k]);
+            const px = w * h;
+            assert.ok(sameBytes(out.colorFrame, frames.subarray(0, px)) && sameBytes(out.reprojectionFrame, frames.subarray(px, 2 * px)) &&
+                      sameBytes(out.priorityFrame, frames.subarray(2 * px, 3 * px)), name + ' frames');
+        }
+        rc.dispose();
+    });
     test('argument validation', () => {
         const rt = new RayTracer(new Vector3(2, 2, 2), buildExample1());
         assert.throws(() => rt.render(0, 10), RangeError);
