@@ -1,0 +1,89 @@
+"""Edge cases through the C ABI on the GPU: empty inputs, ragged sizes, frame sequences and cyclic strips on the
+kernels that the other files exercise only in their usual shape."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle_py as orc          # noqa: E402  (checker only)
+import ptr_amd                   # noqa: E402
+from ptr_amd import synthetic as syn   # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def rdr():
+    r = ptr_amd.Renderer(0)
+    yield r
+    r.close()
+
+
+def test_sequence_of_16_sphere_scenes_two_level_kernel(rdr):
+    """frames of a sequence on the 13..128-sphere kernel (scalar-loaded records), 1-pixel-wide ragged tiles"""
+    torch = pytest.importorskip("torch")
+    base = syn.many_spheres(16)
+    frames = []
+    for f in range(3):
+        s = base.copy(); s[0, 1:14] += 0.7 * f; s[1, 1:14] -= 0.3 * f
+        frames.append(s)
+    rdr.set_camera(None)
+    rdr.set_scene(np.stack(frames)); rdr.set_background(syn.BACKGROUND)
+    w, h = 97, 45
+    out = torch.empty((3, h, w), dtype=torch.int32, device="cuda")
+    rdr.render_device(rdr.params(w, h, flags=0), 0, 3, out.data_ptr())
+    rdr.sync()
+    got = out.cpu().numpy().view(np.uint32)
+    for f in range(3):
+        want = orc.render(frames[f], syn.BACKGROUND, w, h, flags=0).reshape(h, w)
+        assert np.array_equal(got[f], want), f
+
+
+def test_extension_mode_on_cyclic_strips(rdr, scenes):
+    """strips address pixels (and Philox counters) by global row: the parts re-assemble to the whole frame"""
+    torch = pytest.importorskip("torch")
+    sc = scenes["example1"]
+    rdr.set_camera(None); rdr.set_elements(sc["elements"]); rdr.set_background(sc["background"])
+    w, h = 128, 70
+    full = rdr.render(w, h, flags=ptr_amd.MODE_EXACT_F64, max_depth=3, spp=2, seed=9).reshape(h, w)
+    got = np.zeros((h, w), dtype=np.uint32)
+    for part in range(3):
+        sp = ptr_amd.StripPart(3, part, 8)
+        rows = sp.global_rows(h)
+        buf = torch.empty((len(rows), w), dtype=torch.int32, device="cuda")
+        p = rdr.params(w, h, 0, len(rows), flags=ptr_amd.MODE_EXACT_F64, max_depth=3, spp=2, seed=9)
+        rdr.render_strips_device(p, sp, 0, 1, buf.data_ptr())
+        rdr.sync()
+        got[rows] = buf.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, full)
+
+
+def test_empty_batches(rdr, scenes):
+    sc = scenes["example1"]
+    rdr.set_elements(sc["elements"]); rdr.set_background(sc["background"])
+    assert rdr.trace_batch_f64(np.zeros((0, 3))).shape == (0, 3)
+    rgb, rgb8, hit, nrm = rdr.trace_samples([0, 0, 0], np.zeros((0, 3)))
+    assert rgb.shape == (0, 3) and rgb8.shape == (0, 3)
+
+
+def test_render_cache_passes_on_an_empty_cache(rdr):
+    w, h = 17, 9
+    cells = (w + 2) * (h + 2)
+    view = np.eye(4).T.ravel(); proj = np.eye(4).T.ravel()
+    age, item_pixel, el, dep = rdr.rc_reproject([0, 0, 0], view, proj, w, h, np.zeros((0, 3)), np.zeros(0))
+    inner = np.zeros((h + 2, w + 2), dtype=bool); inner[1:h + 1, 1:w + 1] = True
+    assert (el.reshape(h + 2, w + 2)[inner] == -1).all() and (dep.reshape(h + 2, w + 2)[inner] == 1e6).all()
+    assert (el.reshape(h + 2, w + 2)[~inner] == -2).all()                      # border untouched
+    out = rdr.rc_shade(w, h, np.full(cells, -1, dtype=np.int32), np.full(cells, 1e6), np.zeros(0), np.zeros((0, 3)))
+    assert out["hist"][1, 255] == w * h and out["hist"].sum() == w * h         # every pixel URGENT
+    assert out["stats"][0] == 0 and out["stats"][1] == 255 * w * h
+    assert (out["color"] == 0xFF000000).all() and (out["priority"] == 0xFFFFFFFF).all()
+
+
+def test_all_items_without_hits_or_outside(rdr):
+    w, h = 16, 16
+    view = np.eye(4).T.ravel(); proj = np.eye(4).T.ravel()
+    hits = np.array([[np.nan, 0, 0], [5.0, 0, 0], [0.0, 0.0, 0.0], [0.25, 0.25, 0.5]])
+    age0 = np.array([1.0, 2.0, 3.0, 4.0])
+    age, item_pixel, el, dep = rdr.rc_reproject([0, 0, 0], view, proj, w, h, hits, age0)
+    want = orc.rc_reproject([0, 0, 0], view, proj, w, h, hits, age0)
+    assert np.array_equal(age, want[0]) and np.array_equal(item_pixel, want[1])
+    assert list(age - age0) == [0.0, 2.0, 4.0, 0.0] and item_pixel[3] >= 0
