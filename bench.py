@@ -122,6 +122,11 @@ def main():
     if backend != "nccl":
         local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
+    # Everything below runs on ONE explicit stream: the render calls get its handle, torch's own kernels and the
+    # RCCL collectives order themselves against torch's current stream.  (The legacy default stream has handle 0,
+    # which the C ABI reads as "use the context's own stream" — a non-blocking stream that neither torch nor RCCL
+    # would wait for.)
+    torch.cuda.set_stream(torch.cuda.Stream())
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -137,6 +142,7 @@ def main():
     rdr.set_scene(np.ascontiguousarray(np.broadcast_to(soa, (frames_total,) + soa.shape)))
     rdr.set_background(bg)
     stream = torch.cuda.current_stream().cuda_stream
+    assert stream != 0
 
     # ---- per-frame work counts from the GPU's own counting kernel (outside the timed region)
     one = torch.empty(WIDTH * HEIGHT, dtype=torch.int32, device="cuda")
@@ -211,6 +217,13 @@ def main():
     main_ms = float(np.mean([k[0] for k in kms]))
     retrace_ms = float(np.mean([k[1] for k in kms]))
 
+    if args.check and rank == 0:
+        whole = torch.empty((HEIGHT, WIDTH), dtype=torch.int32, device="cuda")
+        rdr.render_device(rdr.params(WIDTH, HEIGHT, flags=0), 0, 1, whole.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        got = full[0] if world > 1 else local[0]
+        assert torch.equal(got, whole), "gathered frame differs from the single-GPU frame"
+        print("check ok: gathered frame == single-GPU frame", file=sys.stderr)
     # ---- BASELINE.json configs[1] as written ("depth 5"): an EXTENSION (the reference has no bounce loop,
     # SURVEY.md F1), reported beside the headline, same scene / size / batch, float32 extension kernel
     depth5 = None
@@ -237,13 +250,6 @@ def main():
                   "dtype": "f32", "note": "extension mode, specification in include/ptr.h; not reference behaviour "
                                           "(parity vs the float64 specification: tests/test_gpu_ext.py)"}
 
-    if args.check and rank == 0:
-        whole = torch.empty((HEIGHT, WIDTH), dtype=torch.int32, device="cuda")
-        rdr.render_device(rdr.params(WIDTH, HEIGHT, flags=0), 0, 1, whole.data_ptr(), stream=stream)
-        torch.cuda.synchronize()
-        got = full[0] if world > 1 else local[0]
-        assert torch.equal(got, whole), "gathered frame differs from the single-GPU frame"
-        print("check ok: gathered frame == single-GPU frame", file=sys.stderr)
     if rank == 0:
         share = local_rows / HEIGHT                      # fraction of every frame this rank renders
         total_rays = rays_per_frame * frames_total       # all ranks together, per step

@@ -234,7 +234,9 @@ class Renderer:
         return (out, f32) if want_f32 else out
 
     def render_device(self, p, first_frame, n_frames, d_rgba8, d_rgba32f=None, stream=None):
-        """d_rgba8 / d_rgba32f: device addresses (ints, e.g. tensor.data_ptr()); enqueue only."""
+        """d_rgba8 / d_rgba32f: device addresses (ints, e.g. tensor.data_ptr()); enqueue only.
+        stream: a HIP stream handle; None or 0 = the context's own (non-blocking) stream, which torch's default
+        stream does not wait for — pass torch.cuda.Stream().cuda_stream of the stream the consumers run on."""
         self._check(self._L.ptr_render_device(self._h, C.byref(p), first_frame, n_frames,
                                               C.c_void_p(d_rgba8),
                                               C.c_void_p(d_rgba32f) if d_rgba32f else None,
