@@ -197,6 +197,7 @@ def test_general_camera_vs_oracle_rays(rdr, scenes):
     w, h = 96, 64
     got = rdr.render(w, h, flags=ptr_amd.MODE_EXACT_F64)
     got_h = rdr.render(w, h, flags=0)
+    got_m = rdr.render(w, h, flags=ptr_amd.DEBUG_FORCE_MANY)          # the two-level kernel's packed ray set-up
     angle = orc.lib().orc_reference_angle()
     soa = orc.scene_to_soa(sc["elements"])
     want = np.empty(w * h, dtype=np.uint32)
@@ -211,6 +212,7 @@ def test_general_camera_vs_oracle_rays(rdr, scenes):
     rdr.set_camera(None)
     assert np.array_equal(got, want)
     assert np.array_equal(got_h, want)
+    assert np.array_equal(got_m, want)
 
 
 def test_float32_framebuffer(rdr, scenes):
