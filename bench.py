@@ -34,6 +34,11 @@ FRAMES_PER_GPU = 64
 STRIP = 8
 PEAK_FP32_VALU_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
 PEAK_HBM_GBPS = 8000.0
+# HBM traffic of the float32 kernel per pixel, from the PMC passes of this very command kept under profiles/
+# (r01_summary.md: WRITE_SIZE 547 129.6 KB and FETCH_SIZE 671.3 KB per launch of 64 x 1920 x 1080 pixels; gfx950
+# correction of the guide applied: FETCH_SIZE counts 64 B per 128-B request -> x 2).  Counters cannot be read from
+# inside this process, so the per-launch figure reported below is this measured rate times the launch's pixels.
+MEASURED_HBM_BYTES_PER_PIXEL = (547129.638 * 1024 + 2 * 671.271 * 1024) / (64 * 1920 * 1080)
 
 
 def example1_soa():
@@ -272,7 +277,11 @@ def main():
             "Mpixels_per_s": round(WIDTH * HEIGHT * frames_total * args.steps / elapsed / 1e6, 1),
             "roofline": {"bound": "valu", "kernel": "render_fast_kernel<hybrid>",
                          "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
+                         "traffic": int(MEASURED_HBM_BYTES_PER_PIXEL * WIDTH * local_rows * frames_total),
+                         "traffic_note": "HBM bytes per launch = PMC-measured bytes per pixel (profiles/r01_summary.md, "
+                                         "WRITE_SIZE + 2 x FETCH_SIZE passes of this command) x pixels of this launch; "
+                                         "algorithmic bytes = 4 per pixel",
                          "kernel_ms": round(main_ms, 4), "retrace_kernel_ms": round(retrace_ms, 4),
                          "algorithmic_flops_per_launch": int(launch_flops),
                          "hbm_frac": round(launch_bytes / (main_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
