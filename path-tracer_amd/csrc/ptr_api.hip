@@ -116,7 +116,7 @@ void default_camera(ptr_camera& cam)
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct BlockLayout {
-    uint32_t off_g64, off_m64, off_p32, off_m32, off_lights, off_pairs;
+    uint32_t off_g64, off_m64, off_p32, off_m32, off_lights, off_pairs, off_lrec;
     size_t   bytes;
 };
 
@@ -132,9 +132,12 @@ BlockLayout block_layout(int n)
     L.off_lights = (uint32_t)o; o += align_up(sizeof(int32_t) * (size_t)(n > 0 ? n : 1), 16);
     // room for every element being a light: [n][n + 2] pre-filter records would be quadratic, so the
     // table is sized for at most PTR_MAX_PAIR_LIGHTS lights; further lights are never culled
-    L.off_pairs = (uint32_t)o;
     // (+ 1 row of never-cull records, used by the lights past the cap)
-    o += sizeof(PairQ) * ((size_t)(n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS) + 1) * ((size_t)n + 2);
+    o = align_up(o, 64);
+    L.off_pairs = (uint32_t)o;
+    o += sizeof(PairQ) * ((size_t)(n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS) + 1) * (size_t)pair_stride(n);
+    o = align_up(o, 64);
+    L.off_lrec = (uint32_t)o;   o += sizeof(LightRec) * ((size_t)n + 1);        // + 1: the look-ahead load
     L.bytes = align_up(o, 256);
     return L;
 }
@@ -157,7 +160,7 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
     int32_t* lights = reinterpret_cast<int32_t*>(dst + L.off_lights);
     auto pl = [&](int k, int i) { return soa[(size_t)k * (size_t)n + (size_t)i]; };
 
-    bool needs_exact = false;
+    bool needs_exact = false, self_skip = true;
     int nl = 0;
     for (int i = 0; i < n; i++) {
         const double cx = pl(0, i), cy = pl(1, i), cz = pl(2, i), r = pl(3, i);
@@ -183,8 +186,19 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
         p.kb = (float)(PR_RELD * scale / (PR_RELB * std::sqrt(scale)));
         p.sgn = cc > 0 ? -1.0f : 1.0f;
         p.unsure = (std::fabs(cc) <= 4.0 * PR_RELD * scale) ? 1.0f : 0.0f;
-        p.hmd = (float)(0.5 * PR_RELD * scale);
         p.eb = (float)(PR_RELB * std::sqrt(scale));
+        {
+            // a ray whose float32 b = l.d is below this cannot hit, nor come within the error bound of hitting
+            const double lo = (cc > 0 ? std::sqrt(cc) : 0.0) - PR_RELB * std::sqrt(scale) * (1.0 + 4 * EPS32);
+            float f = (float)lo;
+            if ((double)f > lo) f = std::nextafterf(f, -INFINITY);
+            p.sclo = std::isfinite(lo) ? f : -3.0e38f;
+        }
+        // "a shadow ray never hits the sphere it starts on (from outside)" holds in the reference's float64 arithmetic
+        // while its rounding (2^-52 of the coordinates and of the 1e8 far clip) is far below the 1e-4 shadow bias
+        if (!(std::fabs(cx) + std::fabs(cy) + std::fabs(cz) + rad + std::fabs(org[0]) + std::fabs(org[1]) +
+              std::fabs(org[2]) < 5.0e8) || !(rad > 0))
+            self_skip = false;
         p.r2 = (float)r2;
         p.lnorm = (float)(lnorm * (1.0 + 2 * EPS32) + 2.1e-4);   // upper bound of |l| + shadow bias
         p.inv_r = (float)(1.0 / std::fmax(rad, 1e-30));
@@ -211,15 +225,28 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
                 const double x = reach / D;
                 const double thr = std::sqrt(1.0 - x * x);
                 q.ax = (float)(ax / D); q.ay = (float)(ay / D); q.az = (float)(az / D);
-                q.thr = (float)(thr * (1.0 - 4 * EPS32) - 10 * EPS32);   // rounding of a, of the dot, of thr itself
+                q.thr = (float)(thr * (1.0 - 4 * EPS32) - 13 * EPS32);   // rounding of a, of the dot, of thr itself
             }
-            pairs[(size_t)k * ((size_t)n + 2) + (size_t)j] = q;
+            pairs[(size_t)k * (size_t)pair_stride(n) + (size_t)j] = q;
         }
-        for (int j = n; j < n + 2; j++) pairs[(size_t)k * ((size_t)n + 2) + (size_t)j] = PairQ{0, 0, 0, -1.0f};
+        for (int j = n; j < pair_stride(n); j++) pairs[(size_t)k * (size_t)pair_stride(n) + (size_t)j] = PairQ{0, 0, 0, -1.0f};
     }
     {
         const size_t row = (size_t)(n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS);
-        for (int j = 0; j < n + 2; j++) pairs[row * ((size_t)n + 2) + (size_t)j] = PairQ{0, 0, 0, -1.0f};
+        for (int j = 0; j < pair_stride(n); j++) pairs[row * (size_t)pair_stride(n) + (size_t)j] = PairQ{0, 0, 0, -1.0f};
+    }
+    {
+        LightRec* lrec = reinterpret_cast<LightRec*>(dst + L.off_lrec);
+        for (int k = 0; k < nl; k++) {
+            const SphereP32& q = p32[lights[k]];
+            const SphereM32& m = m32[lights[k]];
+            LightRec r;
+            std::memset(&r, 0, sizeof r);
+            r.lx = q.lx; r.ly = q.ly; r.lz = q.lz; r.lnorm = q.lnorm;
+            r.er = m.er; r.eg = m.eg; r.eb = m.eb; r.emax = m.emax;
+            r.element = lights[k];
+            lrec[k] = r;
+        }
     }
     for (int k = 0; k < 3; k++) {
         h->bg64[k] = bg[k];
@@ -229,6 +256,7 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
     h->n_lights = nl;
     h->bg_packed = pack_js(bg[0], bg[1], bg[2]);
     h->needs_exact = needs_exact ? 1u : 0u;
+    h->self_skip = self_skip ? 1u : 0u;
     h->off_g64 = L.off_g64; h->off_m64 = L.off_m64; h->off_p32 = L.off_p32;
     h->off_m32 = L.off_m32; h->off_lights = L.off_lights;
     return needs_exact;
@@ -315,7 +343,7 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
     a.frame_stride = c->frame_stride;
     {
         const BlockLayout L = block_layout(c->n_spheres);
-        a.off_p32 = L.off_p32; a.off_m32 = L.off_m32; a.off_lights = L.off_lights; a.off_pairs = L.off_pairs;
+        a.off_p32 = L.off_p32; a.off_m32 = L.off_m32; a.off_lights = L.off_lights; a.off_pairs = L.off_pairs; a.off_lrec = L.off_lrec;
         a.n = c->n_spheres;
     }
     a.first_frame = first_frame;
@@ -341,6 +369,22 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
     a.camf.ox = (float)(-a.cam.angle * a.cam.aspect);
     a.camf.sy = (float)(-2.0 * a.cam.inv_h * a.cam.angle);
     a.camf.oy = (float)(a.cam.angle);
+    {
+        // Tile culling of the float32 kernel: a wave's pixels are an 8 x 16 block of the image when its 16 local rows
+        // are consecutive image rows.  Unnormalised directions D = xx R + yy U + F differ from the tile centre's by at
+        // most rho, and |D| >= dmin (distance of the image plane from the eye), so sin(angle) <= rho / dmin.
+        const double* R = c->cam.right; const double* U = c->cam.up; const double* F = c->cam.forward;
+        const double nx = R[1] * U[2] - R[2] * U[1], ny = R[2] * U[0] - R[0] * U[2], nz = R[0] * U[1] - R[1] * U[0];
+        const double nn = std::sqrt(nx * nx + ny * ny + nz * nz);
+        const double dmin = nn > 0 ? std::fabs(F[0] * nx + F[1] * ny + F[2] * nz) / nn : 0.0;
+        const double rho = 3.5 * std::fabs((double)a.camf.sx) * std::sqrt(R[0] * R[0] + R[1] * R[1] + R[2] * R[2]) +
+                           (0.5 * PTR_TILE_H * PTR_FAST_PPL - 0.5) * std::fabs((double)a.camf.sy) * std::sqrt(U[0] * U[0] + U[1] * U[1] + U[2] * U[2]);
+        const double sn = dmin > 0 ? 1.02 * rho / dmin + 1e-6 : 2.0;
+        const bool rows_consecutive = a.n_parts <= 1 || a.strip_h % (PTR_TILE_H * PTR_FAST_PPL) == 0;
+        a.cull_on = (rows_consecutive && sn < 0.5) ? 1 : 0;
+        a.cull_sin = (float)(sn * (1.0 + 1e-6));
+        a.cull_cos = (float)(std::sqrt(std::fmax(0.0, 1.0 - sn * sn)) * (1.0 - 1e-6));
+    }
     a.out8 = d_out8;
     a.out32f = d_out32f;
     unsigned char* words = static_cast<unsigned char*>(c->words.ptr);

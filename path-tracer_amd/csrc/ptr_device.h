@@ -35,7 +35,8 @@ struct alignas(16) FrameHeader {          // 128 bytes
     float    bg32[3];
     float    pad0;
     uint32_t off_g64, off_m64, off_p32, off_m32, off_lights, off_pad;   // byte offsets in block
-    uint32_t pad1[10];
+    uint32_t self_skip;                   // 1: coordinates are small enough for the "own sphere never shadows" proof
+    uint32_t pad1[9];
 };
 static_assert(sizeof(FrameHeader) == 128, "FrameHeader layout");
 
@@ -58,7 +59,8 @@ struct alignas(64) SphereP32 {
     // group 2: only when some lane of the wave hits the sphere
     float sgn;            // -1: outside, nearest root is b - thc;  +1: inside, root is b + thc
     float unsure;         // 1.0f: |cc| too small to trust its sign -> any hit on it is re-traced
-    float hmd;            // md / 2:  |dt| <= hmd / thc + eb
+    float sclo;           // lower bound of the b = l.d of any ray that can hit or be within the error bound of hitting:
+                          //   origin outside: sqrt(cc) - eb, rounded down; inside: -eb  (one compare per ray and sphere)
     float eb;
     // group 3: winner refinement (per-lane gather)
     float inv_r;          // 1 / radius
@@ -69,11 +71,23 @@ static_assert(sizeof(SphereP32) == 64, "SphereP32 layout");
 // material, gathered per lane for the winning sphere; scmax/emax = largest channel
 struct alignas(16) SphereM32 { float sr, sg, sb, scmax, er, eg, eb, emax; };
 
-// Shadow pre-filter, one record per (light k, element j), laid out [k][n + 2]:
+// Shadow pre-filter, one record per (light k, element j), laid out [k][pair_stride(n)] (rows padded with
+// never-cull records to a multiple of 4 records, so a row can be read 16 floats at a time):
 // a = unit vector from the light's centre to element j's centre, thr = lower bound of |L.a| for
 // which the line through the light with direction L can come within r_j (+ shadow bias) of C_j.
 // A shadow ray towards light k can only hit element j if |L.a| + (error of L) >= thr.
 struct alignas(16) PairQ { float ax, ay, az, thr; };
+__host__ __device__ inline int pair_stride(int n) { return (n + 2 + 3) & ~3; }
+
+// One record per light, scene order, for the float32 kernel's light loop: everything a light contributes, found
+// without first looking up which element it is (one 64-byte scalar load, requested one light ahead).
+struct alignas(64) LightRec {
+    float lx, ly, lz, lnorm;      // camera-relative centre, |l| (padded as SphereP32::lnorm)
+    float er, eg, eb, emax;       // emission, largest channel (padded as SphereM32::emax)
+    int32_t element;              // index of the element
+    int32_t pad[7];
+};
+static_assert(sizeof(LightRec) == 64, "LightRec layout");
 
 struct FrameView {
     const FrameHeader* h;
@@ -116,6 +130,7 @@ struct RenderArgs {
     const unsigned char* scenes;     // frame blocks, frame_stride bytes apart
     uint64_t  frame_stride;
     uint32_t  off_p32, off_m32, off_lights, off_pairs;   // byte offsets inside a frame block (same for every frame)
+    uint32_t  off_lrec, off_pad2;
     int32_t   n;                     // elements per frame
     int32_t   first_frame, n_frames;
     int32_t   width, height, start_y, scan_height;
@@ -124,6 +139,8 @@ struct RenderArgs {
     uint64_t  out_frame_stride;      // pixels between consecutive frames in out8 / out32f
     CameraArgs cam;
     CameraF32  camf;
+    float     cull_cos, cull_sin;    // float32 kernel: every ray of a wave's 8 x 16 tile is within this angle of the
+    int32_t   cull_on;               //   tile's centre ray (bound, padded); cull_on 0: tiles are not contiguous, no culling
     uint32_t* out8;                  // n_frames * width * scan_height
     float*    out32f;                // nullable, n_frames * width * scan_height * 4
     uint32_t* queue;                 // hybrid: n_queues sub-queues of global pixel ids: full re-traces fill a

@@ -22,6 +22,8 @@ typedef const FrameHeader PTR_CONST* ConstHeader;
 typedef const int32_t PTR_CONST* ConstI32;
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef const volatile f4 PTR_CONST* ConstF4;      // a SphereP32 record = 4 x f4
+typedef float f16 __attribute__((ext_vector_type(16)));
+typedef const f16 PTR_CONST* ConstF16;             // a LightRec
 
 // the 12 leading floats of a SphereP32 record (see ptr_device.h for the field names)
 struct P32Q { f4 g0, g1, g2; };
@@ -52,6 +54,26 @@ __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x);
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ unsigned long long ballot(bool c) { return __builtin_amdgcn_ballot_w64(c); }
 __device__ __forceinline__ bool lane_of(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
+// lane `l`'s value of v as a wave-uniform value
+__device__ __forceinline__ float readlane_f(float v, int l)
+{ return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+
+// largest value of v (>= 0) over the wave's 64 lanes, as a wave-uniform value: DPP steps inside rows of 16, then across
+__device__ __forceinline__ float wave_max(float v)
+{
+#define PTR_DPP_MAX(ctrl, rows)                                                                                        \
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), \
+                                                                       ctrl, rows, 0xF, false)))
+    PTR_DPP_MAX(0xB1, 0xF);      // quad_perm [1,0,3,2]
+    PTR_DPP_MAX(0x4E, 0xF);      // quad_perm [2,3,0,1]
+    PTR_DPP_MAX(0x141, 0xF);     // row_half_mirror
+    PTR_DPP_MAX(0x140, 0xF);     // row_mirror: every lane holds its row's maximum
+    PTR_DPP_MAX(0x142, 0xA);     // row_bcast:15 into rows 1 and 3
+    PTR_DPP_MAX(0x143, 0xC);     // row_bcast:31 into rows 2 and 3: lane 63 holds the maximum
+#undef PTR_DPP_MAX
+    return readlane_f(v, 63);
+}
 
 // why a pixel was queued (debug build of the kernel only: PTR_DEBUG_REASONS)
 enum : unsigned { WHY_PRIMARY = 1, WHY_CC = 2, WHY_ORDER = 4, WHY_FAR = 8, WHY_SHADOW = 16, WHY_ROUND = 32 };

@@ -274,7 +274,7 @@ __device__ V<float> trace_ext_f32(const unsigned char* block, const RenderArgs& 
                 const int i = clights[kk];
                 const f4 lg = rec0[4 * (size_t)i];
                 const int prow = kk < PTR_MAX_PAIR_LIGHTS ? kk : (n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS);
-                const ConstRec pairs = pairs0 + (size_t)prow * (size_t)(n + 2);
+                const ConstRec pairs = pairs0 + (size_t)prow * (size_t)pair_stride(n);
                 float Lx = lg.x - P.x, Ly = lg.y - P.y, Lz = lg.z - P.z;
                 const float invl = rsq(fmaf(Lz, Lz, fmaf(Ly, Ly, Lx * Lx)));
                 Lx *= invl; Ly *= invl; Lz *= invl;

@@ -31,18 +31,20 @@ struct Pixel {
     F3    d;                    // camera ray direction
     float tnear, t2, etmax;     // nearest / second nearest distance, largest distance error seen
     int   idx;                  // nearest element, -1 = none
+    F3    wl;                   // the nearest element's record so far (copied from the SGPRs when it takes the lead:
+    float wcc, wr2, wlnorm, web; //   no per-lane gather, and no gather latency, after the loop)
 };
 
 // state of a hit pixel during shading
 struct Shade {
     bool  valid;
-    F3    P, N, so;             // hit point, normal, shadow-ray origin (camera-relative)
+    int   self;                 // the element the pixel lies on, seen from outside (-1: none / seen from inside)
+    F3    P, N;                 // hit point, normal (camera-relative)
     float t, eP, eN;
-    SphereM32 mw;
-    float ar, ag, ab, wsum, eLmax;
+    float ar, ag, ab, wsum, eLmax;   // sum over the unblocked lights of emission * N.L per channel, ...
     // per light
     F3    L;
-    float ratio, eL, kL, cL;
+    float ratio, eL;            // N.L, |error of L| (+ 3 eps: see the pre-filter)
     unsigned long long open_m, maybe_m, blocked_m;
 };
 
@@ -58,17 +60,23 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
     const unsigned char* block = a.scenes + (uint64_t)(a.first_frame + frame) * a.frame_stride;
     const ConstHeader hdr = (ConstHeader)(uintptr_t)block;
     const ConstF4 rec0 = (ConstF4)(uintptr_t)(block + a.off_p32);          // uniform reads, 4 f4 per sphere
-    const ConstM32 cm32 = (ConstM32)(uintptr_t)(block + a.off_m32);
-    const ConstI32 clights = (ConstI32)(uintptr_t)(block + a.off_lights);
-    const ConstF4 pairs0 = (ConstF4)(uintptr_t)(block + a.off_pairs);      // [light][n + 2] pre-filter records
+    const ConstF4 pairs0 = (ConstF4)(uintptr_t)(block + a.off_pairs);      // [light][pair_stride(n)] pre-filter records
     const SphereP32* gp32 = reinterpret_cast<const SphereP32*>(block + a.off_p32);   // per-lane gathers
     const SphereM32* gm32 = reinterpret_cast<const SphereM32*>(block + a.off_m32);
     const int n = a.n;
+
+    // lane i's view of sphere record i for the culling step below, requested first: the latency passes during set-up
+    const int li = lane < n ? lane : 0;                // record 0 exists even in an empty scene (zero padding)
+    const float4 cull_g0 = *reinterpret_cast<const float4*>(&gp32[li].lx);   // lx ly lz cc
+    const float4 cull_g1 = *reinterpret_cast<const float4*>(&gp32[li].md);   // md kb r2 lnorm
 
     // ---- this lane's pixels: an 8 x (8*PPL) tile per wave, 32 x (8*PPL) per workgroup ------------
     Pixel px[PPL];
     [[maybe_unused]] unsigned dbg_full_tests = 0, dbg_pre_tests = 0;   // DBG: shadow tests this wave ran
     Unsure<DBG> unsure[PPL];
+    [[maybe_unused]] unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // DBG: clock at the stage boundaries
+    auto stamp = [&](int k) { if constexpr (DBG) ts[k] = __builtin_readcyclecounter(); };
+    stamp(0);
 #pragma unroll
     for (int p = 0; p < PPL; p++) {
         Pixel& q = px[p];
@@ -93,6 +101,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
         const float inv = rsq(dot3(d, d));
         q.d = F3{d.x * inv, d.y * inv, d.z * inv};
         q.tnear = 3.0e38f; q.t2 = 3.0e38f; q.etmax = 0.0f; q.idx = -1;
+        q.wl = F3{0.0f, 0.0f, 0.0f}; q.wcc = 1.0f; q.wr2 = 1.0f; q.wlnorm = 1.0f; q.web = 0.0f;
     }
     {
         bool any_live = false;
@@ -101,45 +110,86 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
         if (ballot(any_live) == 0ull) return;          // wave-uniform exit: the whole wave is outside
     }
 
+    stamp(1);
+    // ---- which spheres can a ray of this wave reach at all? ---------------------------------------
+    // The wave's pixels form an 8 x 16 block of the image, so its rays lie in a narrow cone around the
+    // block's centre ray dc (half-angle bound from the host, cull_sin / cull_cos).  A ray of the cone can
+    // only hit sphere i if the angle between dc and l_i is at most that half-angle plus the sphere's own
+    // angular radius asin(r / |l|):  l.dc >= cos(T) sqrt(cc) - sin(T) r.  Lane i evaluates this for sphere
+    // i (radius enlarged by the error band of the float32 hit test, so a culled sphere is a CERTAIN miss
+    // for every pixel, not an unsure one); the loop below then visits the set bits only.
+    unsigned cand = (1u << n) - 1u;                    // n <= PTR_FAST_MAX_SPHERES
+    if (a.cull_on) {
+        const int x0 = blockIdx.x * PTR_TILE_W + wave * 8, row0 = blockIdx.y * (PTR_TILE_H * PPL);
+        const float xc = fmaf((float)(x0 + 4), a.camf.sx, a.camf.ox);
+        const float yc = fmaf((float)(global_y(a, row0) + PTR_TILE_H * PPL / 2), a.camf.sy, a.camf.oy);
+        F3 dc;
+        if (a.cam.general) {
+            dc.x = fmaf(xc, a.camf.right[0], fmaf(yc, a.camf.up[0], a.camf.fwd[0]));
+            dc.y = fmaf(xc, a.camf.right[1], fmaf(yc, a.camf.up[1], a.camf.fwd[1]));
+            dc.z = fmaf(xc, a.camf.right[2], fmaf(yc, a.camf.up[2], a.camf.fwd[2]));
+        } else {
+            dc = F3{xc, yc, -1.0f};
+        }
+        const float inv = rsq(dot3(dc, dc));
+        const float4 g0 = cull_g0, g1 = cull_g1;
+        const float bc = dot3(F3{g0.x, g0.y, g0.z}, dc) * inv;
+        const float cce = fmaf(-2.0f, g1.x, g0.w);                           // |l|^2 - (r^2 + 2 md)
+        const float sce = __builtin_amdgcn_sqrtf(fmaxf(cce, 0.0f));
+        const float re = __builtin_amdgcn_sqrtf(fmaf(2.0f, g1.x, g1.z));
+        const float K = fmaf(a.cull_cos, sce, -fmaf(a.cull_sin, re, 1e-5f * g1.w));   // 1e-5 |l|: rounding of all of this
+        cand = (unsigned)ballot((lane < n) & ((cce <= 0.0f) | (bc >= K)));
+    }
+
+    stamp(2);
     // ---- nearest hit (RayTracer.js:26-41) -------------------------------------------------------
+    // One compare decides the common case: a ray with b = l.d below sclo (= sqrt(cc) - error of b) misses.
     // disc = b^2 - cc is cheap (cc is per sphere) but cancels; it only has to ORDER the hits here.
     auto primary = [&](const P32Q& q, int i) {
 #pragma unroll
         for (int p = 0; p < PPL; p++) {
             Pixel& r = px[p];
             const float b = fmaf(q.g0.z, r.d.z, fmaf(q.g0.y, r.d.y, q.g0.x * r.d.x));
+            const unsigned long long poss_m = ballot(b >= q.g2.z);
+            if (poss_m == 0ull) continue;              // wave-uniform
             const float disc = fmaf(b, b, -q.g0.w);
             const float m = fminf(b * q.g1.y, disc);   // hit <=> b >= 0 && disc >= 0 <=> m >= 0
             const unsigned long long hit_m = ballot(m >= 0.0f);
-            unsure[p].add_mask(ballot(fabsf(m) <= q.g1.x), WHY_PRIMARY);
+            unsure[p].add_mask(ballot(fabsf(m) <= q.g1.x) & poss_m, WHY_PRIMARY);
             unsure[p].add_mask(q.g2.y != 0.0f ? hit_m : 0ull, WHY_CC);
             if (m >= 0.0f) {                           // skipped by the wave when no lane hits
                 const float s = rsq(disc);
                 const float t = fmaf(q.g2.x, disc * s, b);   // t0, or t1 when t0 < 0 (RayTracer.js:32-34)
-                r.etmax = fmaxf(r.etmax, fmaf(q.g2.z, s, q.g2.w));
+                r.etmax = fmaxf(r.etmax, fmaf(0.5f * q.g1.x, s, q.g2.w));     // |dt| <= md / (2 thc) + eb
                 r.t2 = __builtin_amdgcn_fmed3f(r.tnear, r.t2, t);   // second smallest so far
-                r.idx = t < r.tnear ? i : r.idx;
+                if (t < r.tnear) {                     // strict: the first of equals stays (RayTracer.js:36)
+                    r.idx = i;
+                    r.wl = F3{q.g0.x, q.g0.y, q.g0.z}; r.wcc = q.g0.w; r.wr2 = q.g1.z; r.wlnorm = q.g1.w; r.web = q.g2.w;
+                }
                 r.tnear = fminf(r.tnear, t);
             }
         }
     };
     {
-        // Two record buffers in SGPRs.  Record n exists (the host pads one never-hit record and one
-        // more), so the request for "the next one" needs no bounds logic.
-        ConstF4 rec = rec0;
-        P32Q A = load_p32(rec);
-        for (int i = 0; i < n; i += 2) {
+        // Two record buffers in SGPRs: the next candidate's record is requested before the current one is
+        // used.  Record n exists (zero padding), so "no next candidate" needs no special case.
+        unsigned todo = cand;
+        int i = todo ? __builtin_ctz(todo) : n;
+        P32Q A = load_p32(rec0 + 4 * i);
+        while (todo) {
+            todo &= todo - 1u;
+            const int inext = todo ? __builtin_ctz(todo) : n;
             arrive(A);
-            const P32Q B = load_p32(rec + 4);
+            const P32Q B = load_p32(rec0 + 4 * inext);
             primary(A, i);
             arrive_after(B, px[PPL - 1].tnear);
-            A = load_p32(rec + 8);
-            if (i + 1 < n) primary(B, i + 1);
-            rec += 8;
+            A = B;
+            i = inext;
         }
         arrive(A);
     }
 
+    stamp(3);
     // miss: the background, bit-exact by construction (RayTracer.js:43-46)
     const float bgr = hdr->bg32[0], bgg = hdr->bg32[1], bgb = hdr->bg32[2];
     const uint32_t bg_packed = hdr->bg_packed;
@@ -150,7 +200,6 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
 #pragma unroll
     for (int p = 0; p < PPL; p++) {
         Pixel& r = px[p];
-        cr[p] = bgr; cg[p] = bgg; cb[p] = bgb; packed[p] = bg_packed;
         sh[p].valid = (r.idx >= 0) & r.live;
         // nearest-vs-second ordering, far clip (t < 1e8, RayTracer.js:19,36)
         unsure[p].add_mask(ballot((r.t2 - r.tnear <= 2.0f * r.etmax) & sh[p].valid), WHY_ORDER);
@@ -161,21 +210,26 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
     // Wave-uniform branch: taken when any lane hit something; lanes that missed run along on
     // sphere 0 with every flag and result masked by `valid` (keeps all control flow below scalar).
     if (ballot(any_valid) != 0ull) {
+        // A shadow ray never hits the sphere it starts on when that sphere was hit from outside: its origin is
+        // P + 1e-4 N, at distance r + 1e-4 from the centre, so tca = l.L = -(r + 1e-4) N.L <= 0 whenever the light is
+        // in front (N.L > 0), and should rounding lift tca to 0, d2 = |l|^2 - tca^2 > r^2 by 2e-4 r (Sphere.js:19-25).
+        // The host vouches (self_skip) that float64 rounding at the scene's coordinates is far below that margin.
+        const bool self_ok = hdr->self_skip != 0u;
+        int uni_self = -2;                              // >= 0: every shaded pixel of the wave lies on this element
+        bool uni = true;
 #pragma unroll
         for (int p = 0; p < PPL; p++) {
             Pixel& r = px[p];
             Shade& s = sh[p];
             const int idx = s.valid ? r.idx : 0;
-            // ---- winner, recomputed accurately (per-lane gather of its record) -----------------
+            // ---- winner, recomputed accurately ---------------------------------------------------
             // disc' = r^2 - |l x d|^2 has no cancellation between |l|^2 and b^2, and the nearest
             // root is taken in its cancellation-free form t = cc / (b + thc).
-            const float4 g0 = *reinterpret_cast<const float4*>(&gp32[idx].lx);    // lx ly lz cc
-            const float2 g1 = *reinterpret_cast<const float2*>(&gp32[idx].r2);    // r2 lnorm
-            const float eb_w = gp32[idx].eb;
-            const float2 g3 = *reinterpret_cast<const float2*>(&gp32[idx].inv_r); // inv_r hed
-            s.mw = gm32[idx];
-            const F3 lw{g0.x, g0.y, g0.z};
-            const float cc_w = g0.w, r2_w = g1.x, lnorm_w = g1.y, inv_r = g3.x, hed_w = g3.y;
+            const F3 lw = r.wl;
+            const float cc_w = r.wcc, r2_w = r.wr2, lnorm_w = r.wlnorm, eb_w = r.web;
+            const float inv_r = rsq(fmaxf(r2_w, 1e-30f));
+            // half the error bound of disc' = r^2 - |l x d|^2: 10 eps r |l| + 2 eps r^2 (r from r^2: 2 more eps)
+            const float hed_w = (10.5f * EPS) * (r2_w * inv_r) * lnorm_w + (2.5f * EPS) * r2_w;
             const F3 d = r.d;
             const float b_w = dot3(lw, d);
             const F3 cr3{fmaf(lw.y, d.z, -lw.z * d.y), fmaf(lw.z, d.x, -lw.x * d.z), fmaf(lw.x, d.y, -lw.y * d.x)};
@@ -186,6 +240,15 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
             const float bt = b_w + thc_w;
             const float rbt = rcp(bt);
             const bool outside = cc_w > 0.0f;
+            s.self = (outside & s.valid & self_ok) ? idx : -1;
+            {
+                const unsigned long long vm = ballot(s.valid);
+                if (vm != 0ull) {                       // wave-uniform
+                    const int first = __builtin_amdgcn_readlane(s.self, (int)__builtin_ctzll(vm));
+                    uni = uni & (ballot(s.valid & (s.self != first)) == 0ull) & (uni_self == -2 || uni_self == first);
+                    uni_self = first;
+                }
+            }
             s.t = outside ? cc_w * rbt : bt;
             s.eP = outside ? s.t * fmaf(et_w, rbt, 4.0f * EPS) : fmaf(2.0f * EPS, s.t, et_w);   // |error of P|
 
@@ -196,40 +259,51 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
             const float sg = outside ? inv : -inv;     // inside: d.N > 0 -> revert (RayTracer.js:54-58)
             s.N = F3{N.x * sg, N.y * sg, N.z * sg};
             s.eN = fmaf(s.eP + EPS * (lnorm_w + s.t), inv_r, 3.0f * EPS);   // |error of N|
-            s.so = F3{fmaf(s.N.x, (float)PTR_BIAS, s.P.x), fmaf(s.N.y, (float)PTR_BIAS, s.P.y),
-                      fmaf(s.N.z, (float)PTR_BIAS, s.P.z)};
             s.ar = 0.0f; s.ag = 0.0f; s.ab = 0.0f; s.wsum = 0.0f; s.eLmax = 0.0f;
         }
+        if (!uni) uni_self = -2;
+        stamp(4);
 
         // ---- direct light + binary shadow (RayTracer.js:61-91) ---------------------------------
         // one shadow test of sphere record pj for every pixel slot
-        auto shadow = [&](const P32H& pj) {
+        auto shadow = [&](const P32H& pj, int j) {
+            if (j == uni_self) return;                 // the whole wave stands on element j
             if constexpr (DBG) dbg_pre_tests++;
             // Pre-filter: the shadow ray leaves (within the 1e-4 bias) along the line through the
             // light's centre, so it can only reach element j if that line does: |L.a| >= thr, with
             // the error of L added on the safe side.  Most (light, element) pairs fail this for every
             // lane of the wave, and the whole test below is skipped.
-            unsigned long long near_m = 0ull;
+            unsigned long long near_m = 0ull, pass_m[PPL];
 #pragma unroll
             for (int p = 0; p < PPL; p++) {
                 const Shade& s = sh[p];
                 const float c = fmaf(pj.pa.z, s.L.z, fmaf(pj.pa.y, s.L.y, pj.pa.x * s.L.x));
-                near_m |= ballot(fabsf(c) + s.cL >= pj.pa.w) & s.open_m;   // thr carries 5 more eps of slack
+                pass_m[p] = ballot(fabsf(c) + s.eL >= pj.pa.w) & s.open_m;   // thr carries 8 more eps of slack
+                near_m |= pass_m[p];
             }
             if (near_m == 0ull) return;
+            if (uni_self == -2) {                      // mixed wave: lanes standing on j need no test of j
+                near_m = 0ull;
+#pragma unroll
+                for (int p = 0; p < PPL; p++) near_m |= pass_m[p] & ~ballot(sh[p].self == j);
+                if (near_m == 0ull) return;
+            }
             if constexpr (DBG) dbg_full_tests++;
 #pragma unroll
             for (int p = 0; p < PPL; p++) {
                 Shade& s = sh[p];
-                const F3 lj{pj.g0.x - s.so.x, pj.g0.y - s.so.y, pj.g0.z - s.so.z};
+                // shadow-ray origin P + 1e-4 N (RayTracer.js:74), rebuilt here: full tests are rare, registers are not
+                const F3 so{fmaf(s.N.x, (float)PTR_BIAS, s.P.x), fmaf(s.N.y, (float)PTR_BIAS, s.P.y),
+                            fmaf(s.N.z, (float)PTR_BIAS, s.P.z)};
+                const F3 lj{pj.g0.x - so.x, pj.g0.y - so.y, pj.g0.z - so.z};
                 const float bj = dot3(lj, s.L);
                 const float ll = dot3(lj, lj);
                 const float disc = fmaf(bj, bj, pj.g1.z - ll);
                 // error bounds: |lj| <= A, 4 d(lj) <= dlj4, d(bj) <= ebj, d(disc) <= band
                 const float A = pj.g1.w + s.t;                       // lnorm (padded on the host) + t
                 const float dlj4 = fmaf(4.0f * EPS, A, 4.0f * s.eP);
-                const float band = fmaf(ll, s.kL, A * dlj4);
-                const float ebj = fmaf(A, s.cL, dlj4);
+                const float band = fmaf(ll, fmaf(2.0f, s.eL, 10.0f * EPS), A * dlj4);
+                const float ebj = fmaf(A, s.eL + 3.0f * EPS, dlj4);
                 // certain any-hit (RayTracer.js:77-81) / possible hit
                 const unsigned long long certain = ballot(bj > ebj) & ballot(disc > band);
                 const unsigned long long possible = ballot(bj >= -ebj) & ballot(disc >= -band);
@@ -245,72 +319,109 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
             for (int p = 0; p < PPL; p++) m |= sh[p].open_m;
             return m == 0ull;
         };
-        // occluders j0 .. j1-1 (the light itself is left out by the caller, RayTracer.js:76)
-        auto shadow_range = [&](ConstF4 pairs, int j0, int j1) {
-            if (j0 >= j1) return;
-            ConstF4 rec = rec0 + 4 * j0;
-            ConstF4 pr = pairs + j0;
-            P32H A = load_p32h(rec, pr);
-            for (int j = j0; j < j1; j += 2) {
-                if (all_closed()) break;
+        // Phase 1 for one light, once per WAVE: the shadow rays of the wave's open lanes lie in a cone around one of
+        // them (axis = the first open lane's L, half-width dmax = the largest |L - axis| + error of L over the open
+        // lanes, found by a cross-lane max).  The line through the light along L can reach element j only if
+        // |a_j . L| >= thr_j (PairQ), and |a_j . L| <= |a_j . axis| + dmax: lane j tests element j against the cone, and
+        // the ballot is a wave-uniform bit per occluder, "some open lane may reach it".  One compare -> mask round
+        // trip per light instead of one per occluder.
+        auto cone_prefilter = [&](const float4 pq) -> unsigned {
+            const unsigned long long o0 = sh[0].open_m;
+            const bool first = o0 != 0ull || PPL == 1;                       // wave-uniform
+            const Shade& sa = sh[first ? 0 : PPL - 1];
+            const int src = (int)__builtin_ctzll(first ? o0 : sa.open_m);
+            const float ax = readlane_f(sa.L.x, src), ay = readlane_f(sa.L.y, src), az = readlane_f(sa.L.z, src);
+            float dev = 0.0f;
+#pragma unroll
+            for (int p = 0; p < PPL; p++) {
+                const Shade& s = sh[p];
+                const float dx = s.L.x - ax, dy = s.L.y - ay, dz = s.L.z - az;
+                const float e = __builtin_amdgcn_sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx))) + s.eL;
+                dev = fmaxf(dev, lane_of(s.open_m) ? e : 0.0f);
+            }
+            const float dmax = fmaf(wave_max(dev), 1.000001f, 1e-7f);       // rounding of the above
+            const float c = fmaf(pq.z, az, fmaf(pq.y, ay, pq.x * ax));
+            return (unsigned)ballot((fabsf(c) + dmax >= pq.w) & (lane < n));  // thr carries 8 more eps of slack
+        };
+        // Phase 2: the full test for the occluders whose bit is set (next record requested before the current is used)
+        auto shadow_bits = [&](ConstF4 pairs, unsigned need) {
+            int j = need ? __builtin_ctz(need) : n;
+            P32H A = load_p32h(rec0 + 4 * j, pairs + j);
+            while (need) {
+                need &= need - 1u;
+                const int jn = need ? __builtin_ctz(need) : n;
                 arrive(A);
-                const P32H B = load_p32h(rec + 4, pr + 1);
-                shadow(A);
+                const P32H B = load_p32h(rec0 + 4 * jn, pairs + jn);
+                shadow(A, j);
                 arrive_after(B, sh[PPL - 1].open_m);
-                A = load_p32h(rec + 8, pr + 2);
-                if (j + 1 < j1) shadow(B);
-                rec += 8;
-                pr += 2;
+                A = B;
+                j = jn;
+                if (all_closed()) break;
             }
             arrive(A);
         };
 
         const int nl = hdr->n_lights;
+        const ConstM32 cm32 = (ConstM32)(uintptr_t)(block + a.off_m32);
+        const ConstI32 clights = (ConstI32)(uintptr_t)(block + a.off_lights);
         for (int k = 0; k < nl; k++) {
             const int i = clights[k];
             // lights past the table's capacity share a record that never culls (thr < 0)
             const int prow = k < PTR_MAX_PAIR_LIGHTS ? k : (n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS);
-            const ConstF4 pairs = pairs0 + (size_t)prow * (size_t)(n + 2);
+            const ConstF4 pairs = pairs0 + (size_t)prow * (size_t)pair_stride(n);
             const P32H pl = load_p32h(rec0 + 4 * i, pairs);
+            const F3 lpos{pl.g0.x, pl.g0.y, pl.g0.z};
+            const float llnorm = pl.g1.w;
             const float ler = cm32[i].er, leg = cm32[i].eg, leb = cm32[i].eb, lemax = cm32[i].emax;
+            // lane j's (light k, element j) pre-filter record, requested now for the cone test after the set-up
+            const float4 pq = reinterpret_cast<const float4*>(block + a.off_pairs)[(size_t)prow * (size_t)pair_stride(n) + (size_t)li];
 #pragma unroll
             for (int p = 0; p < PPL; p++) {
                 Shade& s = sh[p];
-                F3 L{pl.g0.x - s.P.x, pl.g0.y - s.P.y, pl.g0.z - s.P.z};
+                F3 L{lpos.x - s.P.x, lpos.y - s.P.y, lpos.z - s.P.z};
                 const float invl = rsq(dot3(L, L));
                 s.L = F3{L.x * invl, L.y * invl, L.z * invl};
-                s.eL = fmaf(fmaf(EPS, pl.g1.w + s.t, s.eP), invl, 3.0f * EPS);   // |error of L|
+                s.eL = fmaf(fmaf(EPS, llnorm + s.t, s.eP), invl, 3.0f * EPS);   // |error of L|
                 s.ratio = dot3(s.N, s.L);
-                s.kL = fmaf(2.0f, s.eL, 10.0f * EPS);
-                s.cL = s.eL + 3.0f * EPS;
                 // lane masks: lanes still needing a verdict / inside a bound / blocked in float32
                 s.open_m = ballot((s.ratio > 0.0f) & s.valid);
                 s.maybe_m = 0ull; s.blocked_m = 0ull;
             }
-            shadow_range(pairs, 0, i);
-            shadow_range(pairs, i + 1, n);
+            if (!all_closed()) {
+                // every element but the light itself (RayTracer.js:76) and the one the whole wave stands on
+                unsigned need = cone_prefilter(pq) & ~(1u << i);
+                if (uni_self >= 0) need &= ~(1u << uni_self);
+                shadow_bits(pairs, need);
+            }
 #pragma unroll
             for (int p = 0; p < PPL; p++) {
                 Shade& s = sh[p];
                 // A "maybe" only matters if no certain hit blocks the light anyway.
                 unsure[p].add_mask(s.open_m & s.maybe_m, WHY_SHADOW);
                 if (lane_of(s.open_m & ~s.blocked_m)) {
-                    s.ar = fmaf(s.mw.sr * ler, s.ratio, s.ar);
-                    s.ag = fmaf(s.mw.sg * leg, s.ratio, s.ag);
-                    s.ab = fmaf(s.mw.sb * leb, s.ratio, s.ab);
+                    s.ar = fmaf(ler, s.ratio, s.ar);
+                    s.ag = fmaf(leg, s.ratio, s.ag);
+                    s.ab = fmaf(leb, s.ratio, s.ab);
                     s.wsum += lemax;
                     s.eLmax = fmaxf(s.eLmax, s.eL);
                 }
             }
         }
 
+        stamp(5);
+        // the winners' materials, gathered only now (all requests first): surfaceColor * (sum over lights) + emission
+        // (RayTracer.js:85-93)
+        SphereM32 mws[PPL];
+#pragma unroll
+        for (int p = 0; p < PPL; p++) mws[p] = gm32[sh[p].valid ? px[p].idx : 0];
 #pragma unroll
         for (int p = 0; p < PPL; p++) {
             Shade& s = sh[p];
-            const float hr = s.ar + s.mw.er, hg = s.ag + s.mw.eg, hb = s.ab + s.mw.eb;   // RayTracer.js:93
+            const SphereM32 mw = mws[p];
+            const float hr = fmaf(mw.sr, s.ar, mw.er), hg = fmaf(mw.sg, s.ag, mw.eg), hb = fmaf(mw.sb, s.ab, mw.eb);
             // ---- clamp, round, pack (RayTracer.js:179-192) with a rounding bound ----------------
             // |error of N.L| <= eN + eL (+ rounding of the dot and of the sums, 8 eps)
-            const float band = 255.0f * fmaf(s.mw.scmax * s.wsum, s.eN + s.eLmax + 8.0f * EPS, 4.0f * EPS * s.mw.emax) + 2e-5f;
+            const float band = 255.0f * fmaf(mw.scmax * s.wsum, s.eN + s.eLmax + 10.0f * EPS, 4.0f * EPS * mw.emax) + 2e-5f;
             const float vr = fminf(hr, 1.0f) * 255.0f, vg = fminf(hg, 1.0f) * 255.0f, vb = fminf(hb, 1.0f) * 255.0f;
             const float fr = floorf(vr), fg = floorf(vg), fb = floorf(vb);
             const float qr = vr - fr, qg = vg - fg, qb = vb - fb;
@@ -319,20 +430,26 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
             const uint32_t r8 = (uint32_t)(qr >= 0.5f ? fr + 1.0f : fr);
             const uint32_t g8 = (uint32_t)(qg >= 0.5f ? fg + 1.0f : fg);
             const uint32_t b8 = (uint32_t)(qb >= 0.5f ? fb + 1.0f : fb);
-            if (s.valid) {
-                packed[p] = (255u << 24) | (b8 << 16) | (g8 << 8) | r8;
-                cr[p] = hr; cg[p] = hg; cb[p] = hb;
-            }
+            packed[p] = s.valid ? (255u << 24) | (b8 << 16) | (g8 << 8) | r8 : bg_packed;
+            cr[p] = s.valid ? hr : bgr; cg[p] = s.valid ? hg : bgg; cb[p] = s.valid ? hb : bgb;
         }
+    } else {
+#pragma unroll
+        for (int p = 0; p < PPL; p++) { cr[p] = bgr; cg[p] = bgg; cb[p] = bgb; packed[p] = bg_packed; }
     }
 
+    stamp(6);
     // ---- stores ---------------------------------------------------------------------------------
     const uint32_t bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
 #pragma unroll
     for (int p = 0; p < PPL; p++) {
         const Pixel& r = px[p];
         if (!r.live) continue;
-        if constexpr (DBG) packed[p] = unsure[p].why() | (dbg_full_tests << 8) | (dbg_pre_tests << 16);
+        if constexpr (DBG) {
+            packed[p] = unsure[p].why() | (dbg_full_tests << 8) | (dbg_pre_tests << 16);
+            // 0x2000: the first 6 pixels of the wave's first row carry the clocks spent in stages 0..5 instead
+            if ((a.flags & 0x2000u) && p == 0 && lane < 6) packed[p] = (uint32_t)(ts[lane + 1] - ts[lane]);
+        }
         long long idx_out = (long long)a.width * r.row + r.x;
         if (quirk) idx_out -= a.width;
         if (idx_out >= 0) out8[idx_out] = packed[p];

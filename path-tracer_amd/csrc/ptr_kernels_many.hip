@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_many_kernel(RenderArgs a)
     for (int k = 0; k < nl; k++) {
         const int il = clights[k];
         const int prow = k < PTR_MAX_PAIR_LIGHTS ? k : (n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS);
-        const PairQ* pairs = gpairs + (size_t)prow * (size_t)(n + 2);
+        const PairQ* pairs = gpairs + (size_t)prow * (size_t)pair_stride(n);
         const f4 lg0 = rec0[4 * (size_t)il], lg1 = rec0[4 * (size_t)il + 1];
         const float ler = cm32[il].er, leg = cm32[il].eg, leb = cm32[il].eb, lemax = cm32[il].emax;
         // per pixel: k2s > NEVER <=> the lane still needs a verdict ("open"); maybe = some occluder's test was
@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_many_kernel(RenderArgs a)
                     shadow_l2(jj, q.x, q.y, q.z, w);
                 }
             };
-            ConstF4 pr = (ConstF4)(uintptr_t)(block + a.off_pairs) + (size_t)prow * (size_t)(n + 2);
+            ConstF4 pr = (ConstF4)(uintptr_t)(block + a.off_pairs) + (size_t)prow * (size_t)pair_stride(n);
             f4 A = pr[0];
             for (int j = 0; j < n && wave_open; j += 2) {
                 arrive1(A);

@@ -87,3 +87,90 @@ def test_all_items_without_hits_or_outside(rdr):
     want = orc.rc_reproject([0, 0, 0], view, proj, w, h, hits, age0)
     assert np.array_equal(age, want[0]) and np.array_equal(item_pixel, want[1])
     assert list(age - age0) == [0.0, 2.0, 4.0, 0.0] and item_pixel[3] >= 0
+
+
+def _small_scene(rng, n, floor):
+    soa = np.zeros((12, n))
+    soa[0] = rng.uniform(-12, 12, n); soa[1] = rng.uniform(-5, 8, n); soa[2] = rng.uniform(-45, -6, n)
+    soa[3] = rng.uniform(0.3, 3.5, n)
+    soa[4:7] = rng.uniform(0.0, 1.0, (3, n))
+    lights = rng.random(n) < 0.25
+    lights[rng.integers(0, n)] = True
+    soa[9:12, lights] = rng.uniform(0.2, 2.0, (3, int(lights.sum())))
+    if floor:
+        soa[0:4, 0] = [0, -1000 - rng.uniform(2, 6), -20, 1000]
+        soa[9:12, 0] = 0
+    return soa
+
+
+def test_few_sphere_kernel_random_scenes_ragged_sizes(rdr):
+    """1..12 spheres (the SGPR-record kernel: tile culling, own-sphere skip, cone pre-filter of the occluders) at sizes
+    that leave ragged tiles; also a scene the own-sphere proof does not cover (a zero-radius element switches it off)."""
+    rng = np.random.default_rng(7012)
+    rdr.set_camera(None)
+    for trial in range(10):
+        n = int(rng.integers(1, 13))
+        soa = _small_scene(rng, n, trial % 2 == 0)
+        if trial == 9:
+            soa[3, -1] = 0.0
+        bg = rng.uniform(0, 1.5, 3)
+        w, h = int(rng.integers(33, 300)), int(rng.integers(17, 200))
+        rdr.set_scene(soa); rdr.set_background(bg)
+        got = rdr.render(w, h, flags=0)
+        want = orc.render(soa, bg, w, h, flags=0, threads=8)
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, f"trial {trial} (n={n}, {w}x{h}): {bad.size} pixels differ, first {bad[:5]}"
+
+
+def test_few_sphere_kernel_moved_camera_and_inside_a_sphere(rdr):
+    """general camera (the culling cone follows it) from several places, one of them inside a big sphere"""
+    rng = np.random.default_rng(7013)
+    soa = _small_scene(rng, 9, True)
+    soa[0:4, 1] = [1.0, 1.0, -3.0, 9.0]          # camera positions below are inside this one
+    bg = np.array([0.3, 0.5, 0.9])
+    rdr.set_scene(soa); rdr.set_background(bg)
+    w, h = 120, 72
+    angle = orc.lib().orc_reference_angle()
+    for org, look in (((0.5, 1.5, -2.0), (-0.3, -0.2, -1.0)), ((14.0, 6.0, 4.0), (-0.5, -0.25, -1.0)),
+                      ((-3.0, 0.5, -60.0), (0.1, 0.0, 1.0))):
+        org = np.array(org); fwd = np.array(look); fwd /= np.linalg.norm(fwd)
+        right = np.cross(fwd, [0, 1, 0]); right /= np.linalg.norm(right)
+        up = np.cross(right, fwd)
+        rdr.set_camera(org, right, up, fwd)
+        got = rdr.render(w, h, flags=0)
+        want = np.empty(w * h, dtype=np.uint32)
+        for y in range(h):
+            for x in range(w):
+                xx = (2 * ((x + 0.5) * (1 / w)) - 1) * angle * (w / h)
+                yy = (1 - 2 * ((y + 0.5) * (1 / h))) * angle
+                d = xx * right + yy * up + fwd
+                l2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2]
+                d = d * (1 / np.sqrt(l2))
+                want[y * w + x] = orc.pack(orc.trace(soa, bg, org, d))
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, f"camera at {org}: {bad.size} pixels differ, first {bad[:5]}"
+    rdr.set_camera(None)
+
+
+@pytest.mark.parametrize("n_parts,strip", [(2, 16), (3, 32), (2, 24)])
+def test_strips_with_whole_tiles_use_the_culling_path(rdr, scenes, n_parts, strip):
+    """strip heights that are multiples of the wave tile's 16 rows keep tile culling on; others switch it off
+    (test_gpu_parity.py covers those): the bytes must not depend on it"""
+    torch = pytest.importorskip("torch")
+    sc = scenes["example1"]
+    rdr.set_camera(None)
+    rdr.set_elements(sc["elements"]); rdr.set_background(sc["background"])
+    w, h = 200, 150
+    want = orc.render(orc.scene_to_soa(sc["elements"]), sc["background"], w, h, flags=0, threads=8).reshape(h, w)
+    full = np.zeros((h, w), dtype=np.uint32)
+    max_rows = ptr_amd.StripPart(n_parts, 0, strip).local_rows(h)
+    for part in range(n_parts):
+        sp = ptr_amd.StripPart(n_parts, part, strip)
+        rows = sp.global_rows(h)
+        buf = torch.zeros((max_rows, w), dtype=torch.int32, device="cuda")
+        p = rdr.params(w, h, 0, len(rows), flags=0)
+        rdr.render_strips_device(p, sp, 0, 1, buf.data_ptr(), stream=torch.cuda.current_stream().cuda_stream,
+                                 frame_stride_px=max_rows * w)
+        torch.cuda.synchronize()
+        full[rows] = buf.cpu().numpy().view(np.uint32)[: len(rows)]
+    assert np.array_equal(full, want)
