@@ -49,7 +49,7 @@ struct Shade {
 };
 
 template <bool HYBRID, bool DBG, int PPL>
-__global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
+__global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) render_fast_kernel(RenderArgs a)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int frame = blockIdx.z;
@@ -262,6 +262,25 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
             s.ar = 0.0f; s.ag = 0.0f; s.ab = 0.0f; s.wsum = 0.0f; s.eLmax = 0.0f;
         }
         if (!uni) uni_self = -2;
+        // The wave's shadow-ray origins lie in a ball: centre = the first shaded lane's hit point, radius = the largest
+        // distance of a shaded lane's P from it, plus the error of P and the 1e-4 bias (used by cone_prefilter).
+        float pcx, pcy, pcz, prad;
+        {
+            const unsigned long long v0 = ballot(sh[0].valid);
+            const bool first = v0 != 0ull || PPL == 1;
+            const Shade& sa = sh[first ? 0 : PPL - 1];
+            const int src = (int)__builtin_ctzll(first ? v0 : ballot(sa.valid));
+            pcx = readlane_f(sa.P.x, src); pcy = readlane_f(sa.P.y, src); pcz = readlane_f(sa.P.z, src);
+            float dev = 0.0f;
+#pragma unroll
+            for (int p = 0; p < PPL; p++) {
+                const Shade& s = sh[p];
+                const float dx = s.P.x - pcx, dy = s.P.y - pcy, dz = s.P.z - pcz;
+                const float e = __builtin_amdgcn_sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx))) + s.eP;
+                dev = fmaxf(dev, s.valid ? e : 0.0f);
+            }
+            prad = fmaf(wave_max(dev), 1.000001f, 1.01e-4f);
+        }
         stamp(4);
 
         // ---- direct light + binary shadow (RayTracer.js:61-91) ---------------------------------
@@ -325,7 +344,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
         // |a_j . L| >= thr_j (PairQ), and |a_j . L| <= |a_j . axis| + dmax: lane j tests element j against the cone, and
         // the ballot is a wave-uniform bit per occluder, "some open lane may reach it".  One compare -> mask round
         // trip per light instead of one per occluder.
-        auto cone_prefilter = [&](const float4 pq) -> unsigned {
+        auto cone_prefilter = [&](const float4 pq, const float4 cj) -> unsigned {
             const unsigned long long o0 = sh[0].open_m;
             const bool first = o0 != 0ull || PPL == 1;                       // wave-uniform
             const Shade& sa = sh[first ? 0 : PPL - 1];
@@ -341,7 +360,12 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
             }
             const float dmax = fmaf(wave_max(dev), 1.000001f, 1e-7f);       // rounding of the above
             const float c = fmaf(pq.z, az, fmaf(pq.y, ay, pq.x * ax));
-            return (unsigned)ballot((fabsf(c) + dmax >= pq.w) & (lane < n));  // thr carries 8 more eps of slack
+            // ... and element j lies BEHIND every shadow ray of the wave when tca = (C_j - origin) . L < 0 for all of
+            // them (Sphere.js:18-19: tca < 0 is a miss wherever the origin is):  tca <= lcj.axis + |lcj| dmax + prad
+            const F3 lcj{cj.x - pcx, cj.y - pcy, cj.z - pcz};          // lane j: element j's centre from the ball's centre
+            const float lcn = __builtin_amdgcn_sqrtf(dot3(lcj, lcj)) * 1.000001f + 1e-6f;
+            const float tca_up = fmaf(lcn, dmax, dot3(lcj, F3{ax, ay, az})) + prad * 1.000001f;
+            return (unsigned)ballot((fabsf(c) + dmax >= pq.w) & (tca_up >= 0.0f) & (lane < n));  // thr carries 8 more eps of slack
         };
         // Phase 2: the full test for the occluders whose bit is set (next record requested before the current is used)
         auto shadow_bits = [&](ConstF4 pairs, unsigned need) {
@@ -375,6 +399,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
             const float ler = cm32[i].er, leg = cm32[i].eg, leb = cm32[i].eb, lemax = cm32[i].emax;
             // lane j's (light k, element j) pre-filter record, requested now for the cone test after the set-up
             const float4 pq = reinterpret_cast<const float4*>(block + a.off_pairs)[(size_t)prow * (size_t)pair_stride(n) + (size_t)li];
+            const float4 cj = *reinterpret_cast<const float4*>(&gp32[li].lx);      // ... and element j's centre
 #pragma unroll
             for (int p = 0; p < PPL; p++) {
                 Shade& s = sh[p];
@@ -389,7 +414,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_fast_kernel(RenderArgs a)
             }
             if (!all_closed()) {
                 // every element but the light itself (RayTracer.js:76) and the one the whole wave stands on
-                unsigned need = cone_prefilter(pq) & ~(1u << i);
+                unsigned need = cone_prefilter(pq, cj) & ~(1u << i);
                 if (uni_self >= 0) need &= ~(1u << uni_self);
                 shadow_bits(pairs, need);
             }
