@@ -116,7 +116,7 @@ void default_camera(ptr_camera& cam)
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct BlockLayout {
-    uint32_t off_g64, off_m64, off_p32, off_m32, off_lights, off_pairs, off_lrec;
+    uint32_t off_g64, off_m64, off_p32, off_m32, off_lights, off_pairs;
     size_t   bytes;
 };
 
@@ -136,8 +136,6 @@ BlockLayout block_layout(int n)
     o = align_up(o, 64);
     L.off_pairs = (uint32_t)o;
     o += sizeof(PairQ) * ((size_t)(n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS) + 1) * (size_t)pair_stride(n);
-    o = align_up(o, 64);
-    L.off_lrec = (uint32_t)o;   o += sizeof(LightRec) * ((size_t)n + 1);        // + 1: the look-ahead load
     L.bytes = align_up(o, 256);
     return L;
 }
@@ -235,19 +233,6 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
         const size_t row = (size_t)(n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS);
         for (int j = 0; j < pair_stride(n); j++) pairs[row * (size_t)pair_stride(n) + (size_t)j] = PairQ{0, 0, 0, -1.0f};
     }
-    {
-        LightRec* lrec = reinterpret_cast<LightRec*>(dst + L.off_lrec);
-        for (int k = 0; k < nl; k++) {
-            const SphereP32& q = p32[lights[k]];
-            const SphereM32& m = m32[lights[k]];
-            LightRec r;
-            std::memset(&r, 0, sizeof r);
-            r.lx = q.lx; r.ly = q.ly; r.lz = q.lz; r.lnorm = q.lnorm;
-            r.er = m.er; r.eg = m.eg; r.eb = m.eb; r.emax = m.emax;
-            r.element = lights[k];
-            lrec[k] = r;
-        }
-    }
     for (int k = 0; k < 3; k++) {
         h->bg64[k] = bg[k];
         h->bg32[k] = (float)bg[k];
@@ -343,7 +328,7 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
     a.frame_stride = c->frame_stride;
     {
         const BlockLayout L = block_layout(c->n_spheres);
-        a.off_p32 = L.off_p32; a.off_m32 = L.off_m32; a.off_lights = L.off_lights; a.off_pairs = L.off_pairs; a.off_lrec = L.off_lrec;
+        a.off_p32 = L.off_p32; a.off_m32 = L.off_m32; a.off_lights = L.off_lights; a.off_pairs = L.off_pairs;
         a.n = c->n_spheres;
     }
     a.first_frame = first_frame;

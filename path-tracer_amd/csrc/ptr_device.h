@@ -79,16 +79,6 @@ struct alignas(16) SphereM32 { float sr, sg, sb, scmax, er, eg, eb, emax; };
 struct alignas(16) PairQ { float ax, ay, az, thr; };
 __host__ __device__ inline int pair_stride(int n) { return (n + 2 + 3) & ~3; }
 
-// One record per light, scene order, for the float32 kernel's light loop: everything a light contributes, found
-// without first looking up which element it is (one 64-byte scalar load, requested one light ahead).
-struct alignas(64) LightRec {
-    float lx, ly, lz, lnorm;      // camera-relative centre, |l| (padded as SphereP32::lnorm)
-    float er, eg, eb, emax;       // emission, largest channel (padded as SphereM32::emax)
-    int32_t element;              // index of the element
-    int32_t pad[7];
-};
-static_assert(sizeof(LightRec) == 64, "LightRec layout");
-
 struct FrameView {
     const FrameHeader* h;
     const SphereG64* g64;
@@ -130,7 +120,6 @@ struct RenderArgs {
     const unsigned char* scenes;     // frame blocks, frame_stride bytes apart
     uint64_t  frame_stride;
     uint32_t  off_p32, off_m32, off_lights, off_pairs;   // byte offsets inside a frame block (same for every frame)
-    uint32_t  off_lrec, off_pad2;
     int32_t   n;                     // elements per frame
     int32_t   first_frame, n_frames;
     int32_t   width, height, start_y, scan_height;

@@ -22,8 +22,6 @@ typedef const FrameHeader PTR_CONST* ConstHeader;
 typedef const int32_t PTR_CONST* ConstI32;
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef const volatile f4 PTR_CONST* ConstF4;      // a SphereP32 record = 4 x f4
-typedef float f16 __attribute__((ext_vector_type(16)));
-typedef const f16 PTR_CONST* ConstF16;             // a LightRec
 
 // the 12 leading floats of a SphereP32 record (see ptr_device.h for the field names)
 struct P32Q { f4 g0, g1, g2; };
@@ -59,19 +57,33 @@ __device__ __forceinline__ bool lane_of(unsigned long long m) { return __builtin
 __device__ __forceinline__ float readlane_f(float v, int l)
 { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 
-// largest value of v (>= 0) over the wave's 64 lanes, as a wave-uniform value: DPP steps inside rows of 16, then across
+// max of two values that are known not to be NaN: fmaxf() spends an extra instruction per operand on quieting NaNs
+__device__ __forceinline__ float fmax_raw(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// largest value of v (>= 0, no NaN) over the wave's 64 lanes, as a wave-uniform value: DPP steps inside rows of 16
+// lanes, then across rows; lane 63 ends up with the maximum.  (Each step reads what the previous one wrote: the
+// two wait states a DPP read needs after a VALU write are spelled out, the compiler does not look inside.)
 __device__ __forceinline__ float wave_max(float v)
 {
-#define PTR_DPP_MAX(ctrl, rows)                                                                                        \
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), \
-                                                                       ctrl, rows, 0xF, false)))
-    PTR_DPP_MAX(0xB1, 0xF);      // quad_perm [1,0,3,2]
-    PTR_DPP_MAX(0x4E, 0xF);      // quad_perm [2,3,0,1]
-    PTR_DPP_MAX(0x141, 0xF);     // row_half_mirror
-    PTR_DPP_MAX(0x140, 0xF);     // row_mirror: every lane holds its row's maximum
-    PTR_DPP_MAX(0x142, 0xA);     // row_bcast:15 into rows 1 and 3
-    PTR_DPP_MAX(0x143, 0xC);     // row_bcast:31 into rows 2 and 3: lane 63 holds the maximum
-#undef PTR_DPP_MAX
+    asm volatile("s_nop 1\n"
+                 "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+                 "s_nop 1"
+                 : "+v"(v));
     return readlane_f(v, 63);
 }
 

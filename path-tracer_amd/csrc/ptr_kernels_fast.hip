@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
             if (m >= 0.0f) {                           // skipped by the wave when no lane hits
                 const float s = rsq(disc);
                 const float t = fmaf(q.g2.x, disc * s, b);   // t0, or t1 when t0 < 0 (RayTracer.js:32-34)
-                r.etmax = fmaxf(r.etmax, fmaf(0.5f * q.g1.x, s, q.g2.w));     // |dt| <= md / (2 thc) + eb
+                r.etmax = fmax_raw(r.etmax, fmaf(0.5f * q.g1.x, s, q.g2.w));     // |dt| <= md / (2 thc) + eb
                 r.t2 = __builtin_amdgcn_fmed3f(r.tnear, r.t2, t);   // second smallest so far
                 if (t < r.tnear) {                     // strict: the first of equals stays (RayTracer.js:36)
                     r.idx = i;
@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
                 const Shade& s = sh[p];
                 const float dx = s.P.x - pcx, dy = s.P.y - pcy, dz = s.P.z - pcz;
                 const float e = __builtin_amdgcn_sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx))) + s.eP;
-                dev = fmaxf(dev, s.valid ? e : 0.0f);
+                dev = fmax_raw(dev, s.valid ? e : 0.0f);
             }
             prad = fmaf(wave_max(dev), 1.000001f, 1.01e-4f);
         }
@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
                 const Shade& s = sh[p];
                 const float dx = s.L.x - ax, dy = s.L.y - ay, dz = s.L.z - az;
                 const float e = __builtin_amdgcn_sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx))) + s.eL;
-                dev = fmaxf(dev, lane_of(s.open_m) ? e : 0.0f);
+                dev = fmax_raw(dev, lane_of(s.open_m) ? e : 0.0f);
             }
             const float dmax = fmaf(wave_max(dev), 1.000001f, 1e-7f);       // rounding of the above
             const float c = fmaf(pq.z, az, fmaf(pq.y, ay, pq.x * ax));
@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
                     s.ag = fmaf(leg, s.ratio, s.ag);
                     s.ab = fmaf(leb, s.ratio, s.ab);
                     s.wsum += lemax;
-                    s.eLmax = fmaxf(s.eLmax, s.eL);
+                    s.eLmax = fmax_raw(s.eLmax, s.eL);
                 }
             }
         }
