@@ -65,6 +65,13 @@ __device__ __forceinline__ float fmax_raw(float a, float b)
     return r;
 }
 
+__device__ __forceinline__ float fmin_raw(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // largest value of v (>= 0, no NaN) over the wave's 64 lanes, as a wave-uniform value: DPP steps inside rows of 16
 // lanes, then across rows; lane 63 ends up with the maximum.  (Each step reads what the previous one wrote: the
 // two wait states a DPP read needs after a VALU write are spelled out, the compiler does not look inside.)

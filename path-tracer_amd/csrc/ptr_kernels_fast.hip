@@ -447,16 +447,16 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
             // ---- clamp, round, pack (RayTracer.js:179-192) with a rounding bound ----------------
             // |error of N.L| <= eN + eL (+ rounding of the dot and of the sums, 8 eps)
             const float band = 255.0f * fmaf(mw.scmax * s.wsum, s.eN + s.eLmax + 10.0f * EPS, 4.0f * EPS * mw.emax) + 2e-5f;
-            const float vr = fminf(hr, 1.0f) * 255.0f, vg = fminf(hg, 1.0f) * 255.0f, vb = fminf(hb, 1.0f) * 255.0f;
-            const float fr = floorf(vr), fg = floorf(vg), fb = floorf(vb);
-            const float qr = vr - fr, qg = vg - fg, qb = vb - fb;
-            const float nearest = fminf(fminf(fabsf(qr - 0.5f), fabsf(qg - 0.5f)), fabsf(qb - 0.5f));
+            // Math.round(v) = floor(v + 0.5); v + 0.5 is exact in float32 for 0.5 <= v < 256, and below 0.5 it can only
+            // round across 1.0 within the band that is re-traced anyway
+            const float vr = fmin_raw(hr, 1.0f) * 255.0f, vg = fmin_raw(hg, 1.0f) * 255.0f, vb = fmin_raw(hb, 1.0f) * 255.0f;
+            const float qr = __builtin_amdgcn_fractf(vr) - 0.5f, qg = __builtin_amdgcn_fractf(vg) - 0.5f,
+                        qb = __builtin_amdgcn_fractf(vb) - 0.5f;
+            const float nearest = fminf(fminf(fabsf(qr), fabsf(qg)), fabsf(qb));
             unsure[p].add_mask(ballot((nearest <= band) & s.valid), WHY_ROUND);
-            const uint32_t r8 = (uint32_t)(qr >= 0.5f ? fr + 1.0f : fr);
-            const uint32_t g8 = (uint32_t)(qg >= 0.5f ? fg + 1.0f : fg);
-            const uint32_t b8 = (uint32_t)(qb >= 0.5f ? fb + 1.0f : fb);
+            const uint32_t r8 = (uint32_t)(vr + 0.5f), g8 = (uint32_t)(vg + 0.5f), b8 = (uint32_t)(vb + 0.5f);
             packed[p] = s.valid ? (255u << 24) | (b8 << 16) | (g8 << 8) | r8 : bg_packed;
-            cr[p] = s.valid ? hr : bgr; cg[p] = s.valid ? hg : bgg; cb[p] = s.valid ? hb : bgb;
+            if (a.out32f) { cr[p] = s.valid ? hr : bgr; cg[p] = s.valid ? hg : bgg; cb[p] = s.valid ? hb : bgb; }
         }
     } else {
 #pragma unroll
