@@ -423,13 +423,14 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
                 Shade& s = sh[p];
                 // A "maybe" only matters if no certain hit blocks the light anyway.
                 unsure[p].add_mask(s.open_m & s.maybe_m, WHY_SHADOW);
-                if (lane_of(s.open_m & ~s.blocked_m)) {
-                    s.ar = fmaf(ler, s.ratio, s.ar);
-                    s.ag = fmaf(leg, s.ratio, s.ag);
-                    s.ab = fmaf(leb, s.ratio, s.ab);
-                    s.wsum += lemax;
-                    s.eLmax = fmax_raw(s.eLmax, s.eL);
-                }
+                // branch-free: an unlit lane adds zeros (selects cost less than switching lanes off and on again)
+                const bool lit = lane_of(s.open_m & ~s.blocked_m);
+                const float wr = lit ? s.ratio : 0.0f;
+                s.ar = fmaf(ler, wr, s.ar);
+                s.ag = fmaf(leg, wr, s.ag);
+                s.ab = fmaf(leb, wr, s.ab);
+                s.wsum += lit ? lemax : 0.0f;
+                s.eLmax = fmax_raw(s.eLmax, lit ? s.eL : 0.0f);
             }
         }
 
