@@ -157,17 +157,18 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
             const unsigned long long hit_m = ballot(m >= 0.0f);
             unsure[p].add_mask(ballot(fabsf(m) <= q.g1.x) & poss_m, WHY_PRIMARY);
             unsure[p].add_mask(q.g2.y != 0.0f ? hit_m : 0ull, WHY_CC);
-            if (m >= 0.0f) {                           // skipped by the wave when no lane hits
-                const float s = rsq(disc);
-                const float t = fmaf(q.g2.x, disc * s, b);   // t0, or t1 when t0 < 0 (RayTracer.js:32-34)
-                r.etmax = fmax_raw(r.etmax, fmaf(0.5f * q.g1.x, s, q.g2.w));     // |dt| <= md / (2 thc) + eb
-                r.t2 = __builtin_amdgcn_fmed3f(r.tnear, r.t2, t);   // second smallest so far
-                if (t < r.tnear) {                     // strict: the first of equals stays (RayTracer.js:36)
-                    r.idx = i;
-                    r.wl = F3{q.g0.x, q.g0.y, q.g0.z}; r.wcc = q.g0.w; r.wr2 = q.g1.z; r.wlnorm = q.g1.w; r.web = q.g2.w;
-                }
-                r.tnear = fminf(r.tnear, t);
+            // Branch-free for the lanes that miss (they carry t = "never" and add no error): switching lanes off and on
+            // costs more than the two selects.  Only the copy of a new leader's record is predicated.
+            const bool hit = m >= 0.0f;
+            const float s = rsq(disc);                 // (NaN where disc < 0: selected away below)
+            const float t = hit ? fmaf(q.g2.x, disc * s, b) : 3.0e38f;      // t0, or t1 when t0 < 0 (RayTracer.js:32-34)
+            r.etmax = fmax_raw(r.etmax, hit ? fmaf(0.5f * q.g1.x, s, q.g2.w) : 0.0f);     // |dt| <= md / (2 thc) + eb
+            r.t2 = __builtin_amdgcn_fmed3f(r.tnear, r.t2, t);   // second smallest so far
+            if (t < r.tnear) {                         // strict: the first of equals stays (RayTracer.js:36)
+                r.idx = i;
+                r.wl = F3{q.g0.x, q.g0.y, q.g0.z}; r.wcc = q.g0.w; r.wr2 = q.g1.z; r.wlnorm = q.g1.w; r.web = q.g2.w;
             }
+            r.tnear = fmin_raw(r.tnear, t);
         }
     };
     {
