@@ -146,12 +146,21 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
     // One compare decides the common case: a ray with b = l.d below sclo (= sqrt(cc) - error of b) misses.
     // disc = b^2 - cc is cheap (cc is per sphere) but cancels; it only has to ORDER the hits here.
     auto primary = [&](const P32Q& q, int i) {
+        float bs[PPL];
+        unsigned long long poss[PPL], any_m = 0ull;
+#pragma unroll
+        for (int p = 0; p < PPL; p++) {
+            const Pixel& r = px[p];
+            bs[p] = fmaf(q.g0.z, r.d.z, fmaf(q.g0.y, r.d.y, q.g0.x * r.d.x));
+            poss[p] = ballot(bs[p] >= q.g2.z);
+            any_m |= poss[p];
+        }
+        if (any_m == 0ull) return;                     // wave-uniform: ONE compare -> mask -> branch trip per sphere
 #pragma unroll
         for (int p = 0; p < PPL; p++) {
             Pixel& r = px[p];
-            const float b = fmaf(q.g0.z, r.d.z, fmaf(q.g0.y, r.d.y, q.g0.x * r.d.x));
-            const unsigned long long poss_m = ballot(b >= q.g2.z);
-            if (poss_m == 0ull) continue;              // wave-uniform
+            const float b = bs[p];
+            const unsigned long long poss_m = poss[p];
             const float disc = fmaf(b, b, -q.g0.w);
             const float m = fminf(b * q.g1.y, disc);   // hit <=> b >= 0 && disc >= 0 <=> m >= 0
             const unsigned long long hit_m = ballot(m >= 0.0f);
