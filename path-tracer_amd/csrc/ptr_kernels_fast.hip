@@ -201,8 +201,6 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
 
     stamp(3);
     // miss: the background, bit-exact by construction (RayTracer.js:43-46)
-    const float bgr = hdr->bg32[0], bgg = hdr->bg32[1], bgb = hdr->bg32[2];
-    const uint32_t bg_packed = hdr->bg_packed;
     float cr[PPL], cg[PPL], cb[PPL];
     uint32_t packed[PPL];
     Shade sh[PPL];
@@ -379,20 +377,16 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
         };
         // Phase 2: the full test for the occluders whose bit is set (next record requested before the current is used)
         auto shadow_bits = [&](ConstF4 pairs, unsigned need) {
-            int j = need ? __builtin_ctz(need) : n;
-            P32H A = load_p32h(rec0 + 4 * j, pairs + j);
+            // (no look-ahead here: a wave rarely has a second set bit, and a second record buffer costs 12 SGPRs that
+            // the register allocator would have to spill)
             while (need) {
+                const int j = __builtin_ctz(need);
                 need &= need - 1u;
-                const int jn = need ? __builtin_ctz(need) : n;
+                const P32H A = load_p32h(rec0 + 4 * j, pairs + j);
                 arrive(A);
-                const P32H B = load_p32h(rec0 + 4 * jn, pairs + jn);
                 shadow(A, j);
-                arrive_after(B, sh[PPL - 1].open_m);
-                A = B;
-                j = jn;
                 if (all_closed()) break;
             }
-            arrive(A);
         };
 
         const int nl = hdr->n_lights;
@@ -445,6 +439,9 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
         }
 
         stamp(5);
+        // the background (RayTracer.js:43-46, bit-exact by construction) is read only here: four SGPRs fewer to carry
+        const float bgr = hdr->bg32[0], bgg = hdr->bg32[1], bgb = hdr->bg32[2];
+        const uint32_t bg_packed = hdr->bg_packed;
         // the winners' materials, gathered only now (all requests first): surfaceColor * (sum over lights) + emission
         // (RayTracer.js:85-93)
         SphereM32 mws[PPL];
@@ -471,7 +468,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
         }
     } else {
 #pragma unroll
-        for (int p = 0; p < PPL; p++) { cr[p] = bgr; cg[p] = bgg; cb[p] = bgb; packed[p] = bg_packed; }
+        for (int p = 0; p < PPL; p++) { cr[p] = hdr->bg32[0]; cg[p] = hdr->bg32[1]; cb[p] = hdr->bg32[2]; packed[p] = hdr->bg_packed; }
     }
 
     stamp(6);
