@@ -49,7 +49,7 @@ struct Shade {
 };
 
 template <bool HYBRID, bool DBG, int PPL>
-__global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) render_fast_kernel(RenderArgs a)
+__global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(7))) render_fast_kernel(RenderArgs a)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int frame = blockIdx.z;
