@@ -175,11 +175,11 @@ def main():
         row_index = [torch.as_tensor(ptr_amd.StripPart(world, r, STRIP).global_rows(HEIGHT), device="cuda")
                      for r in range(world)]
 
-    def step(flags=0):
+    def step(flags=0, gather=True):
         p.flags = flags
         rdr.render_strips_device(p, part, 0, frames_total, local.data_ptr(), stream=stream,
                                  frame_stride_px=max_rows * WIDTH)
-        if world > 1:
+        if world > 1 and gather:
             if backend == "nccl":
                 dist.gather(local, gathered, dst=0)
             else:                                  # rehearsal: stage through the host
@@ -212,6 +212,18 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+
+    # ---- N > 1: the same steps without the exchange, timed the same way, so that the line shows what the gather costs
+    render_only = None
+    if world > 1:
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(gather=False)
+        fence()
+        ro = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+        dist.all_reduce(ro, op=dist.ReduceOp.MAX)
+        render_only = float(ro.item())
 
     # ---- dominant kernel's own duration: HIP events on the launch stream, live, same workload
     kms = []
@@ -288,6 +300,14 @@ def main():
                          "note": "FP32 vector-ALU bound (SURVEY.md 8d): no dense contraction, 4 B/pixel of HBM "
                                  "traffic; achieved = algorithmic FLOPs of the reference's control flow"},
         }
+        if render_only is not None:
+            out["phases"] = {
+                "render_only_ms_per_step": round(render_only / args.steps * 1e3, 4),
+                "render_only_Mrays_per_s": round(total_rays * args.steps / render_only / 1e6, 1),
+                "gather_and_reinterleave_ms_per_step": round((elapsed - render_only) / args.steps * 1e3, 4),
+                "gathered_bytes_per_step_into_rank0": int(4 * WIDTH * HEIGHT * frames_total * (world - 1) / world),
+                "note": "at 1 sample per pixel a GPU produces ~0.5 TB/s of pixels; the gather to rank 0 is bound by rank 0's "
+                        "inbound xGMI links, not by the renderers (DESIGN.md section 6)"}
         if depth5 is not None:
             out["extension_depth5"] = depth5
         if world == 1 and not args.no_cpu_baseline:

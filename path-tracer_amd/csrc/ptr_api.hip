@@ -355,17 +355,17 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
     a.camf.sy = (float)(-2.0 * a.cam.inv_h * a.cam.angle);
     a.camf.oy = (float)(a.cam.angle);
     {
-        // Tile culling of the float32 kernel: a wave's pixels are an 8 x 16 block of the image when its 16 local rows
+        // Tile culling of the float32 kernel: a wave's pixels are a 16 x 8 block of the image when its 8 local rows
         // are consecutive image rows.  Unnormalised directions D = xx R + yy U + F differ from the tile centre's by at
         // most rho, and |D| >= dmin (distance of the image plane from the eye), so sin(angle) <= rho / dmin.
         const double* R = c->cam.right; const double* U = c->cam.up; const double* F = c->cam.forward;
         const double nx = R[1] * U[2] - R[2] * U[1], ny = R[2] * U[0] - R[0] * U[2], nz = R[0] * U[1] - R[1] * U[0];
         const double nn = std::sqrt(nx * nx + ny * ny + nz * nz);
         const double dmin = nn > 0 ? std::fabs(F[0] * nx + F[1] * ny + F[2] * nz) / nn : 0.0;
-        const double rho = 3.5 * std::fabs((double)a.camf.sx) * std::sqrt(R[0] * R[0] + R[1] * R[1] + R[2] * R[2]) +
-                           (0.5 * PTR_TILE_H * PTR_FAST_PPL - 0.5) * std::fabs((double)a.camf.sy) * std::sqrt(U[0] * U[0] + U[1] * U[1] + U[2] * U[2]);
+        const double rho = (4.0 * PTR_FAST_PPL - 0.5) * std::fabs((double)a.camf.sx) * std::sqrt(R[0] * R[0] + R[1] * R[1] + R[2] * R[2]) +
+                           (0.5 * PTR_TILE_H - 0.5) * std::fabs((double)a.camf.sy) * std::sqrt(U[0] * U[0] + U[1] * U[1] + U[2] * U[2]);
         const double sn = dmin > 0 ? 1.02 * rho / dmin + 1e-6 : 2.0;
-        const bool rows_consecutive = a.n_parts <= 1 || a.strip_h % (PTR_TILE_H * PTR_FAST_PPL) == 0;
+        const bool rows_consecutive = a.n_parts <= 1 || a.strip_h % PTR_TILE_H == 0;
         a.cull_on = (rows_consecutive && sn < 0.5) ? 1 : 0;
         a.cull_sin = (float)(sn * (1.0 + 1e-6));
         a.cull_cos = (float)(std::sqrt(std::fmax(0.0, 1.0 - sn * sn)) * (1.0 - 1e-6));
@@ -406,12 +406,13 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
     }
     // hybrid: float32 kernel fills the sub-queues, float64 kernel drains them
     const int rpb = many ? many_kernel_rows_per_block() : fast_kernel_rows_per_block();
-    const uint64_t n_blocks = (uint64_t)((p->width + PTR_TILE_W - 1) / PTR_TILE_W) *
+    const int cpb = many ? PTR_TILE_W : fast_kernel_cols_per_block();
+    const uint64_t n_blocks = (uint64_t)((p->width + cpb - 1) / cpb) *
                               (uint64_t)((p->scan_height + rpb - 1) / rpb) * (uint64_t)n_frames;
     uint64_t n_queues = 1;                                     // a power of two (the kernel masks)
     while (n_queues * 2 <= PTR_MAX_QUEUES && n_queues * 8 <= n_blocks) n_queues *= 2;
     // a workgroup can queue at most PTR_BLOCK pixels; sub-queue s serves the workgroups b with (b & (n_queues - 1)) == s
-    const uint64_t sub_capacity = (n_blocks + n_queues - 1) / n_queues * (uint64_t)(PTR_TILE_W * rpb);
+    const uint64_t sub_capacity = (n_blocks + n_queues - 1) / n_queues * (uint64_t)(cpb * rpb);
     PTR_TRY(grow(c, c->queue, (size_t)(n_queues * sub_capacity) * 3 * sizeof(uint32_t)));   // ids + 2 info words
     const bool odd = (c->hybrid_calls & 1u) != 0;
     a.queue = static_cast<uint32_t*>(c->queue.ptr);

@@ -12,7 +12,8 @@ hipError_t launch_trace_batch_exact(const TraceArgs& a, hipStream_t s);
 
 // float32 with uncertainty filter (ptr_kernels_fast.hip); hybrid = queue unsure pixels
 hipError_t launch_render_fast(const RenderArgs& a, int n_frames, bool hybrid, hipStream_t s);
-int fast_kernel_rows_per_block();   // image rows one workgroup of the float32 kernel covers
+int fast_kernel_rows_per_block();   // image rows / columns one workgroup of the float32 kernel covers
+int fast_kernel_cols_per_block();
 
 // float32 for many spheres: sphere list staged through LDS, two-level tests (ptr_kernels_many.hip)
 hipError_t launch_render_many(const RenderArgs& a, int n_frames, bool hybrid, hipStream_t s);

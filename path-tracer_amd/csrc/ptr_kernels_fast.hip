@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
     const float4 cull_g0 = *reinterpret_cast<const float4*>(&gp32[li].lx);   // lx ly lz cc
     const float4 cull_g1 = *reinterpret_cast<const float4*>(&gp32[li].md);   // md kb r2 lnorm
 
-    // ---- this lane's pixels: an 8 x (8*PPL) tile per wave, 32 x (8*PPL) per workgroup ------------
+    // ---- this lane's pixels: an (8*PPL) x 8 tile per wave (the pixel slots side by side: a tile never straddles two 8-row strips), (32*PPL) x 8 per workgroup ------------
     Pixel px[PPL];
     [[maybe_unused]] unsigned dbg_full_tests = 0, dbg_pre_tests = 0;   // DBG: shadow tests this wave ran
     Unsure<DBG> unsure[PPL];
@@ -80,8 +80,8 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
     for (int p = 0; p < PPL; p++) {
         Pixel& q = px[p];
-        q.x = blockIdx.x * PTR_TILE_W + wave * 8 + (lane & 7);
-        q.row = blockIdx.y * (PTR_TILE_H * PPL) + p * PTR_TILE_H + (lane >> 3);
+        q.x = blockIdx.x * (PTR_TILE_W * PPL) + wave * (8 * PPL) + p * 8 + (lane & 7);
+        q.row = blockIdx.y * PTR_TILE_H + (lane >> 3);
         q.live = (q.x < a.width) & (q.row < a.scan_height);
         if (quirk & q.live & (q.row == 0)) {          // RayTracer.js:169: dropped row / untouched last row
             out8[(uint64_t)a.width * (a.scan_height - 1) + q.x] = 0u;
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
 
     stamp(1);
     // ---- which spheres can a ray of this wave reach at all? ---------------------------------------
-    // The wave's pixels form an 8 x 16 block of the image, so its rays lie in a narrow cone around the
+    // The wave's pixels form a 16 x 8 block of the image, so its rays lie in a narrow cone around the
     // block's centre ray dc (half-angle bound from the host, cull_sin / cull_cos).  A ray of the cone can
     // only hit sphere i if the angle between dc and l_i is at most that half-angle plus the sphere's own
     // angular radius asin(r / |l|):  l.dc >= cos(T) sqrt(cc) - sin(T) r.  Lane i evaluates this for sphere
@@ -120,9 +120,9 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
     // for every pixel, not an unsure one); the loop below then visits the set bits only.
     unsigned cand = (1u << n) - 1u;                    // n <= PTR_FAST_MAX_SPHERES
     if (a.cull_on) {
-        const int x0 = blockIdx.x * PTR_TILE_W + wave * 8, row0 = blockIdx.y * (PTR_TILE_H * PPL);
-        const float xc = fmaf((float)(x0 + 4), a.camf.sx, a.camf.ox);
-        const float yc = fmaf((float)(global_y(a, row0) + PTR_TILE_H * PPL / 2), a.camf.sy, a.camf.oy);
+        const int x0 = blockIdx.x * (PTR_TILE_W * PPL) + wave * (8 * PPL), row0 = blockIdx.y * PTR_TILE_H;
+        const float xc = fmaf((float)(x0 + 4 * PPL), a.camf.sx, a.camf.ox);
+        const float yc = fmaf((float)(global_y(a, row0) + PTR_TILE_H / 2), a.camf.sy, a.camf.oy);
         F3 dc;
         if (a.cam.general) {
             dc.x = fmaf(xc, a.camf.right[0], fmaf(yc, a.camf.up[0], a.camf.fwd[0]));
@@ -506,13 +506,14 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
 template <bool HYBRID, bool DBG, int PPL>
 static hipError_t launch_variant(const RenderArgs& a, int n_frames, hipStream_t s)
 {
-    const int th = PTR_TILE_H * PPL;
-    dim3 grid((a.width + PTR_TILE_W - 1) / PTR_TILE_W, (a.scan_height + th - 1) / th, n_frames);
+    const int tw = PTR_TILE_W * PPL;
+    dim3 grid((a.width + tw - 1) / tw, (a.scan_height + PTR_TILE_H - 1) / PTR_TILE_H, n_frames);
     hipLaunchKernelGGL((render_fast_kernel<HYBRID, DBG, PPL>), grid, dim3(PTR_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 
-int fast_kernel_rows_per_block() { return PTR_TILE_H * PTR_FAST_PPL; }
+int fast_kernel_rows_per_block() { return PTR_TILE_H; }
+int fast_kernel_cols_per_block() { return PTR_TILE_W * PTR_FAST_PPL; }
 
 hipError_t launch_render_fast(const RenderArgs& a, int n_frames, bool hybrid, hipStream_t s)
 {

@@ -7,7 +7,7 @@ B=$1; shift
 L=path-tracer_amd/lib/libptr_hip.so
 cp $L /tmp/libA.so
 for round in 1 2 3; do
-    cp /tmp/libA.so $L; echo -n "A: "; timeout -k 10 100 python tools/prof_run.py "$@" | sed 's/.*Mpixel/Mpixel/' || exit 1
-    cp $B $L;           echo -n "B: "; timeout -k 10 100 python tools/prof_run.py "$@" | sed 's/.*Mpixel/Mpixel/' || exit 1
+    cp /tmp/libA.so $L; echo -n "A: "; timeout -k 10 100 python tools/prof_run.py "$@" | sed 's/.*wall ms/wall ms/' || exit 1
+    cp $B $L;           echo -n "B: "; timeout -k 10 100 python tools/prof_run.py "$@" | sed 's/.*wall ms/wall ms/' || exit 1
 done
 cp /tmp/libA.so $L

@@ -27,4 +27,16 @@ for _ in range(steps):
     r.render_device(p, 0, frames, out.data_ptr(), stream=s)
     torch.cuda.synchronize()
     ms.append(r.kernel_ms())
-print("kernel ms (main, retrace):", ms, " Mpixel/s:", frames * WIDTH * HEIGHT / (ms[-1][0] * 1e-3) / 1e6)
+# whole steps back to back (no events, no sync in between): what bench.py times
+import time
+p2 = r.params(WIDTH, HEIGHT, flags=mode)
+for _ in range(3):
+    r.render_device(p2, 0, frames, out.data_ptr(), stream=s)
+torch.cuda.synchronize()
+n2 = max(steps, 20)
+t0 = time.perf_counter()
+for _ in range(n2):
+    r.render_device(p2, 0, frames, out.data_ptr(), stream=s)
+torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / n2 * 1e3
+print("kernel ms (main, retrace):", ms, " wall ms per step: %.4f" % wall, " Mpixel/s:", frames * WIDTH * HEIGHT / (ms[-1][0] * 1e-3) / 1e6)
