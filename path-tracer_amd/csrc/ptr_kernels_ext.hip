@@ -195,12 +195,17 @@ __device__ V<float> trace_ext_f32(const unsigned char* block, const RenderArgs& 
     const float bgx = hdr->bg32[0], bgy = hdr->bg32[1], bgz = hdr->bg32[2];
     constexpr float BIAS = (float)PTR_BIAS;
 
+    // Depth-first expansion with the ray that would be popped next kept in registers: a hit that spawns only a
+    // reflection (the usual case) never touches the stack, which lives in scratch memory; the order of the rays, and
+    // with it the order of the sums, is the specification's.
     ExtRay<float> stack[PTR_EXT_MAX_DEPTH + 2];
-    int top = 1;
-    stack[0] = ExtRay<float>{o0, d0, V<float>{1, 1, 1}, 0};
+    int top = 0;
+    ExtRay<float> r{o0, d0, V<float>{1, 1, 1}, 0};
+    bool have = true;
     float ax = 0.0f, ay = 0.0f, az = 0.0f;
-    while (top > 0) {
-        const ExtRay<float> r = stack[--top];
+    while (have || top > 0) {
+        if (!have) r = stack[--top];
+        have = false;
         // nearest hit (RayTracer.js:26-41)
         float tnear = (float)PTR_INFINITY;
         int e = -1;
@@ -258,14 +263,15 @@ __device__ V<float> trace_ext_f32(const unsigned char* block, const RenderArgs& 
                     c.depth = r.depth + 1;
                 }
             }
-            ExtRay<float>& c = stack[top++];
+            // the reflection is the ray processed next (it would be pushed last and popped first): it stays in r
             const float two = 2.0f * dn;
-            c.o = V<float>{fmaf(N.x, BIAS, P.x), fmaf(N.y, BIAS, P.y), fmaf(N.z, BIAS, P.z)};
             V<float> cd{fmaf(-N.x, two, r.d.x), fmaf(-N.y, two, r.d.y), fmaf(-N.z, two, r.d.z)};
             const float inv = rsq(fmaf(cd.z, cd.z, fmaf(cd.y, cd.y, cd.x * cd.x)));
-            c.d = V<float>{cd.x * inv, cd.y * inv, cd.z * inv};
-            c.w = V<float>{wx * fresnel, wy * fresnel, wz * fresnel};
-            c.depth = r.depth + 1;
+            r.o = V<float>{fmaf(N.x, BIAS, P.x), fmaf(N.y, BIAS, P.y), fmaf(N.z, BIAS, P.z)};
+            r.d = V<float>{cd.x * inv, cd.y * inv, cd.z * inv};
+            r.w = V<float>{wx * fresnel, wy * fresnel, wz * fresnel};
+            r.depth = r.depth + 1;
+            have = true;
         } else {
             // the reference's direct lighting (RayTracer.js:60-91)
             const float sox = fmaf(N.x, BIAS, P.x), soy = fmaf(N.y, BIAS, P.y), soz = fmaf(N.z, BIAS, P.z);

@@ -20,7 +20,8 @@ r = ptr_amd.Renderer(0)
 r.set_scene(np.ascontiguousarray(np.broadcast_to(soa, (frames,) + soa.shape)))
 r.set_background([2.0, 2.0, 2.0])
 out = torch.empty((frames, HEIGHT, WIDTH), dtype=torch.int32, device="cuda")
-p = r.params(WIDTH, HEIGHT, flags=mode | ptr_amd.FLAG_TIMING)
+depth = int(os.environ.get("PTR_PROF_DEPTH", "0"))       # > 0: the extension kernel at that depth
+p = r.params(WIDTH, HEIGHT, flags=mode | ptr_amd.FLAG_TIMING, max_depth=depth)
 s = torch.cuda.current_stream().cuda_stream
 ms = []
 for _ in range(steps):
@@ -29,7 +30,7 @@ for _ in range(steps):
     ms.append(r.kernel_ms())
 # whole steps back to back (no events, no sync in between): what bench.py times
 import time
-p2 = r.params(WIDTH, HEIGHT, flags=mode)
+p2 = r.params(WIDTH, HEIGHT, flags=mode, max_depth=depth)
 for _ in range(3):
     r.render_device(p2, 0, frames, out.data_ptr(), stream=s)
 torch.cuda.synchronize()
