@@ -83,13 +83,17 @@ template <typename T, bool STATS>
 __device__ V<T> trace_ext(const SceneT<T>& sc, V<T> o0, V<T> d0, int max_depth, ExtCounts* k)
 {
     const int n = sc.fv.h->n, nl = sc.fv.h->n_lights;
+    // The ray that would be popped next stays in registers (a reflection is pushed last, so it is processed first):
+    // same rays in the same order, and only a second child travels through the scratch-memory stack.
     ExtRay<T> stack[PTR_EXT_MAX_DEPTH + 2];
-    int top = 1;
-    stack[0] = ExtRay<T>{o0, d0, V<T>{1, 1, 1}, 0};
+    int top = 0;
+    ExtRay<T> r{o0, d0, V<T>{1, 1, 1}, 0};
+    bool have = true;
     V<T> acc{0, 0, 0};
     const V<T> bg = sc.bg();
-    while (top > 0) {
-        const ExtRay<T> r = stack[--top];
+    while (have || top > 0) {
+        if (!have) r = stack[--top];
+        have = false;
         T tnear = T(PTR_INFINITY);
         int e = -1;
         for (int i = 0; i < n; i++) {
@@ -134,14 +138,16 @@ __device__ V<T> trace_ext(const SceneT<T>& sc, V<T> o0, V<T> d0, int max_depth, 
                     c.depth = r.depth + 1;
                 }
             }
-            ExtRay<T>& c = stack[top++];
             xcount<STATS>(k, XT_SECONDARY);
             const T two = 2 * dn;
+            ExtRay<T> c;
             c.o = V<T>{P.x + N.x * T(PTR_BIAS), P.y + N.y * T(PTR_BIAS), P.z + N.z * T(PTR_BIAS)};
             c.d = V<T>{r.d.x - N.x * two, r.d.y - N.y * two, r.d.z - N.z * two};
             c.w = V<T>{wsc.x * fresnel, wsc.y * fresnel, wsc.z * fresnel};
             normalize_v(c.d);
             c.depth = r.depth + 1;
+            r = c;
+            have = true;
         } else {
             // the reference's direct lighting (RayTracer.js:60-91)
             const V<T> so{P.x + N.x * T(PTR_BIAS), P.y + N.y * T(PTR_BIAS), P.z + N.z * T(PTR_BIAS)};
