@@ -288,7 +288,9 @@ typedef struct ptr_rc_shade_params {
  *                   not counted (the reference's arrays hold NaN properties for those)
  *   stats           out: statistics.completeness, statistics.totalPriority, increment of this.totalPriority
  *   *_frame         out, nullable, width * height RGBA8 words each, rows bottom-up as the reference stores them
- * Only the grid's interior is written.  Preconditions: ages are finite integers, colours are bytes.
+ * Only the grid's interior is written.  A border cell may carry an element too (Driver.initializeCache draws pixel
+ * positions from 0, and nothing ever detaches the border): its pixel_depth and pixel_rgb are read as the caller
+ * passes them, its age is the element's.  Preconditions: ages are finite integers, colours are bytes.
  * ptr_rc_shade: HOST pointers, waits.  ptr_rc_shade_device: DEVICE pointers, enqueues on `stream`; d_hist = 768
  * uint32, d_totals = 3 int64 (pixels with an element, totalPriority, this.totalPriority increment).            */
 int ptr_rc_shade(ptr_ctx *ctx, const ptr_rc_shade_params *params, int n_items, const int32_t *pixel_element,

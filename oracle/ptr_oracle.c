@@ -577,8 +577,8 @@ void orc_rc_shade_frame(int width, int height, int n_items, const int32_t *pixel
                     for (int j = -1; j <= 1; j++)
                         if (i != 0 && j != 0) {
                             const int q = (y + j) * stride + (x + i);
-                            const int border = (x + i == 0 || x + i == width + 1 || y + j == 0 || y + j == height + 1);
-                            if (!border && pixel_element[q] >= 0) { sum += pixel_depth[q]; items++; }
+                            /* (border cells count too when they carry an element: the reference never detaches them) */
+                            if (pixel_element[q] >= 0) { sum += pixel_depth[q]; items++; }
                         }
                 if (items != 0) {
                     const double ratio = sum / (items * pixel_depth[p]);
@@ -601,10 +601,9 @@ void orc_rc_shade_frame(int width, int height, int n_items, const int32_t *pixel
                 for (int i = -1; i <= 1; i++)
                     for (int j = -1; j <= 1; j++) {
                         const int q = (y + j) * stride + (x + i);
-                        const int border = (x + i == 0 || x + i == width + 1 || y + j == 0 || y + j == height + 1);
                         const double iw = (i != 0 && j != 0) ? 1 : 2;
                         weight += 0;                                             /* pixel.weight */
-                        if (!border && pixel_element[q] >= 0) {
+                        if (pixel_element[q] >= 0) {
                             r += pixel_rgb[3 * q] * iw; g += pixel_rgb[3 * q + 1] * iw; b += pixel_rgb[3 * q + 2] * iw;
                             age += item_age[pixel_element[q]];
                             cw += iw;

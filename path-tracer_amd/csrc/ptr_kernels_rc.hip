@@ -134,7 +134,8 @@ __global__ void __launch_bounds__(256) rc_cull_kernel(RcShadeArgs a)
 #pragma unroll
         for (int j = -1; j <= 1; j += 2) {
             const int q = (y + j) * stride + (x + i);
-            if (!rc_border(a, x + i, y + j) && a.pixel_element[q] >= 0) { sum += a.pixel_depth[q]; items++; }
+            // (a border cell may carry an element: Driver.initializeCache draws x, y from 0, and nothing detaches the border)
+            if (a.pixel_element[q] >= 0) { sum += a.pixel_depth[q]; items++; }
         }
     if (items != 0) {
         const double ratio = sum / (items * a.pixel_depth[p]);
@@ -174,10 +175,12 @@ __global__ void __launch_bounds__(256) rc_fill_kernel(RcShadeArgs a)
                 for (int j = -1; j <= 1; j++) {
                     const int q = (y + j) * stride + (x + i);
                     const double iw = (i != 0 && j != 0) ? 1 : 2;                   // corner 1, edge and centre 2
-                    if (!rc_border(a, x + i, y + j) && a.pixel_element[q] >= 0) {
+                    if (a.pixel_element[q] >= 0) {
+                        // interior neighbours were staged by the cull kernel; a border cell keeps the colour the caller gave
+                        // it (pixel.color of a border pixel only changes when it is sampled) and its element's current age
                         const uint32_t c = a.pixel_rgb[q];
                         r += (double)(c & 255u) * iw; g += (double)((c >> 8) & 255u) * iw; b += (double)((c >> 16) & 255u) * iw;
-                        age += a.pixel_age[q];
+                        age += rc_border(a, x + i, y + j) ? a.item_age[a.pixel_element[q]] : a.pixel_age[q];
                         cw += iw;
                         items++;
                     }

@@ -476,12 +476,15 @@ static int get_typed(napi_env env, napi_value v, napi_typedarray_type want, void
  * Driver.depthCulling + Driver.fillGaps + the frame getters of the render cache (ptr_rc_shade). */
 static napi_value js_rc_shade(napi_env env, napi_callback_info info)
 {
-    napi_value argv[8];
-    if (!get_args(env, info, 8, argv)) return NULL;
+    napi_value argv[9];
+    if (!get_args_opt(env, info, 8, 9, argv)) return NULL;
     ptr_ctx *ctx = get_ctx(env, argv[0]);
     if (!ctx) return NULL;
     int32_t w, h;
-    void *pel, *pdep, *age, *rgb; size_t npel, npdep, nage, nrgb;
+    void *pel, *pdep, *age, *rgb, *prgb_in = NULL; size_t npel, npdep, nage, nrgb, nprgb = 0;
+    napi_valuetype t9;
+    if (napi_typeof(env, argv[8], &t9) != napi_ok) return NULL;
+    if (t9 != napi_undefined && t9 != napi_null && !get_typed(env, argv[8], napi_uint32_array, &prgb_in, &nprgb)) return NULL;
     double *par; size_t npar;
     if (!get_i32(env, argv[1], &w) || !get_i32(env, argv[2], &h) ||
         !get_typed(env, argv[3], napi_int32_array, &pel, &npel) || !get_typed(env, argv[4], napi_float64_array, &pdep, &npdep) ||
@@ -503,6 +506,10 @@ static napi_value js_rc_shade(napi_env env, napi_callback_info info)
     for (int k = 0; k < 7; k++) {
         NAPI_TRY(env, napi_create_arraybuffer(env, bytes[k], &d[k], &ab[k]));
         memset(d[k], 0, bytes[k]);
+    }
+    if (prgb_in) {                     /* optional 9th argument: the grid's colours before the pass (border cells are read) */
+        if (nprgb != cells) { napi_throw_range_error(env, "PTR_ERR_INVALID", "pixelRgb needs (w+2)*(h+2) entries"); return NULL; }
+        memcpy(d[0], prgb_in, cells * 4);
     }
     int rc = ptr_rc_shade(ctx, &p, (int)nage, (const int32_t *)pel, (const double *)pdep, (double *)age, (const uint32_t *)rgb,
                           (uint32_t *)d[0], (int32_t *)d[1], (uint32_t *)d[2], (double *)d[3], (uint32_t *)d[4], (uint32_t *)d[5], (uint32_t *)d[6]);

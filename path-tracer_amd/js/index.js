@@ -8,3 +8,4 @@ export { default as Camera } from './src/Camera.js';
 export { default as RayTracer } from './src/RayTracer.js';
 export { default as RenderPlanner } from './src/RenderPlanner.js';
 export { default as RenderCache } from './src/RenderCache.js';
+export { default as RenderCacheDriver, RcCamera } from './src/RenderCacheDriver.js';

@@ -67,15 +67,16 @@ export default class RenderCache {
 
     /**
      * Depth culling + gap filling + frames on flat arrays (see include/ptr.h ptr_rc_shade).  itemAge is updated in place.
-     * params: {ageFactor, interpolationZero, interpolationRandom, priorityMax}
+     * params: {ageFactor, interpolationZero, interpolationRandom, priorityMax};  pixelRgbIn (optional, the grid's colours
+     * before the pass): only read for BORDER cells that carry an element (the reference never detaches the border).
      */
-    shadeFrame(width, height, pixelElement, pixelDepth, itemAge, itemRgb, params = {}) {
+    shadeFrame(width, height, pixelElement, pixelDepth, itemAge, itemRgb, params = {}, pixelRgbIn = undefined) {
         if (!this._handle) throw new Error('RenderCache was disposed');
         const p = Float64Array.of(params.ageFactor === undefined ? 1 : params.ageFactor,
                                   params.interpolationZero === undefined ? 20 : params.interpolationZero,
                                   params.interpolationRandom === undefined ? 5 : params.interpolationRandom,
                                   params.priorityMax === undefined ? 255 : params.priorityMax);
-        return this._native.rcShade(this._handle, width, height, pixelElement, pixelDepth, itemAge, itemRgb, p);
+        return this._native.rcShade(this._handle, width, height, pixelElement, pixelDepth, itemAge, itemRgb, p, pixelRgbIn);
     }
 
     /**

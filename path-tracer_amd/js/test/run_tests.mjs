@@ -6,7 +6,7 @@ import fs from 'fs';
 import path from 'path';
 import { fileURLToPath } from 'url';
 import assert from 'assert';
-import { Vector3, Material, Sphere, Scene, Color, Camera, RayTracer, RenderPlanner, RenderCache } from '../index.js';
+import { Vector3, Material, Sphere, Scene, Color, Camera, RayTracer, RenderPlanner, RenderCache, RenderCacheDriver, RcCamera } from '../index.js';
 
 const here = path.dirname(fileURLToPath(import.meta.url));
 const golden = path.join(here, '..', '..', '..', 'tests', 'golden');
@@ -296,6 +296,47 @@ async function gpuTests() {
                       sameBytes(out.priorityFrame, frames.subarray(2 * px, 3 * px)), name + ' frames');
         }
         rc.dispose();
+    });
+    test('RenderCacheDriver.nextFrame(): whole render-cache frames, bit for bit (unmodified Driver.nextFrame goldens)', () => {
+        // tests/golden/rc/frames_*: rendercache-js Driver.nextFrame over several frames with a moving camera and a seeded
+        // Math.random (oracle/gen_golden_rc_frames.mjs); inputs = the camera state per frame, outputs = frames + statistics
+        const idx = JSON.parse(fs.readFileSync(path.join(golden, 'rc', 'frames_index.json')));
+        const desc = JSON.parse(fs.readFileSync(path.join(golden, 'rc', 'index.json'))).scenes.rc_scene2;
+        const realRandom = Math.random;
+        try {
+            for (const [name, m] of Object.entries(idx.cases)) {
+                const rec = f64(path.join('rc', m.file));
+                const fb = fs.readFileSync(path.join(golden, 'rc', m.frames_file));
+                const frames = new Uint32Array(fb.buffer, fb.byteOffset, fb.length / 4);
+                let s = m.seed >>> 0 || 1;                       // the generator's xorshift32
+                Math.random = () => { s ^= s << 13; s >>>= 0; s ^= s >>> 17; s ^= s << 5; s >>>= 0; return s / 4294967296; };
+                const rt = new RayTracer(new Vector3(...desc.background), sceneFrom(desc), undefined, { mode: 'exact' });
+                const cam = new RcCamera(m.width, m.height);
+                const drv = new RenderCacheDriver(rt, cam, m.ratio);
+                drv.prepare(false);
+                const px = m.width * m.height, got = new Uint32Array(px);
+                for (let k = 0; k < m.frames; k++) {
+                    const o = k * m.doubles_per_frame;
+                    cam.setView(rec.subarray(o, o + 3), rec.subarray(o + 3, o + 19), rec.subarray(o + 19, o + 35),
+                                rec.subarray(o + 35, o + 51), rec.subarray(o + 51, o + 67));
+                    drv.nextFrame(k);
+                    const st = drv.statistics, want = rec.subarray(o + 67, o + 74);
+                    const tag = `${name} frame ${k}`;
+                    assert.ok(Number.isNaN(want[0]) ? st.threshold === null : st.threshold === want[0], tag + ' threshold');
+                    assert.strictEqual(st.requestFactor, want[1], tag + ' requestFactor');
+                    assert.strictEqual(st.candidates, want[2], tag + ' candidates');
+                    assert.strictEqual(st.requests, want[3], tag + ' requests');
+                    assert.strictEqual(st.completeness, want[4], tag + ' completeness');
+                    assert.strictEqual(st.totalPriority, want[5], tag + ' totalPriority');
+                    assert.strictEqual(drv.getCacheUsage(), want[6], tag + ' cache usage');
+                    assert.ok(sameBytes(drv.getColorFrame(got), frames.subarray(2 * k * px, (2 * k + 1) * px)), tag + ' colour frame');
+                    assert.ok(sameBytes(drv.getSamplingFrame(got), frames.subarray((2 * k + 1) * px, (2 * k + 2) * px)), tag + ' sampling frame');
+                }
+                drv.dispose(); rt.dispose();
+            }
+        } finally {
+            Math.random = realRandom;
+        }
     });
     test('argument validation', () => {
         const rt = new RayTracer(new Vector3(2, 2, 2), buildExample1());
