@@ -299,7 +299,7 @@ async function gpuTests() {
     });
     test('RenderCacheDriver.nextFrame(): whole render-cache frames, bit for bit (unmodified Driver.nextFrame goldens)', () => {
         // tests/golden/rc/frames_*: rendercache-js Driver.nextFrame over several frames with a moving camera and a seeded
-        // Math.random (oracle/gen_golden_rc_frames.mjs); inputs = the camera state per frame, outputs = frames + statistics
+        // Math.random (the generator is named in frames_index.json); inputs = the camera state per frame, outputs = frames + statistics
         const idx = JSON.parse(fs.readFileSync(path.join(golden, 'rc', 'frames_index.json')));
         const desc = JSON.parse(fs.readFileSync(path.join(golden, 'rc', 'index.json'))).scenes.rc_scene2;
         const realRandom = Math.random;
