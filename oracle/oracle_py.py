@@ -263,13 +263,16 @@ def rc_reproject(cam_from, view, proj, width, height, hits, age, age_factor=1.0,
     return age, item_pixel, el, dep
 
 
-def rc_shade(width, height, pixel_element, pixel_depth, item_age, item_rgb, age_factor=1.0, zero=20.0, rnd=5.0, pmax=255.0):
+def rc_shade(width, height, pixel_element, pixel_depth, item_age, item_rgb, age_factor=1.0, zero=20.0, rnd=5.0, pmax=255.0,
+             pixel_rgb_in=None):
     """depth culling + gap filling + frames; returns dict(age, pixel_rgb, pixel_priority, hist, stats, color, reprojection, priority)"""
     n = len(item_age)
     el = np.ascontiguousarray(pixel_element, dtype=np.int32); dep = np.ascontiguousarray(pixel_depth, dtype=np.float64)
     age = np.array(item_age, dtype=np.float64, copy=True); rgb = np.ascontiguousarray(item_rgb, dtype=np.float64).reshape(-1, 3)
     cells = (width + 2) * (height + 2)
     prgb = np.zeros((cells, 3)); pprio = np.zeros(cells); hist = np.zeros(3 * 256); stats = np.zeros(3)
+    if pixel_rgb_in is not None:                 # border cells that carry an element are read with the colour given here
+        prgb[:] = np.asarray(pixel_rgb_in, dtype=np.float64).reshape(cells, 3)
     frames = [np.zeros(width * height, dtype=np.uint32) for _ in range(3)]
     ip = C.POINTER(C.c_int32); up = C.POINTER(C.c_uint32)
     lib().orc_rc_shade_frame(width, height, n, el.ctypes.data_as(ip), _dp(dep), _dp(age), _dp(rgb), age_factor, zero, rnd, pmax,

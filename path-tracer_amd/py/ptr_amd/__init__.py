@@ -302,8 +302,10 @@ class Renderer:
                                              item_pixel.ctypes.data_as(ip), el.ctypes.data_as(ip), _dp(dep)))
         return age, item_pixel, el, dep
 
-    def rc_shade(self, width, height, pixel_element, pixel_depth, item_age, item_rgb, age_factor=1.0, zero=20.0, rnd=5.0, pmax=255.0):
-        """depth culling + gap filling + frames on host arrays (item_rgb: (n, 3) byte values); same dictionary keys as the tests' CPU checker"""
+    def rc_shade(self, width, height, pixel_element, pixel_depth, item_age, item_rgb, age_factor=1.0, zero=20.0, rnd=5.0, pmax=255.0,
+                 pixel_rgb_in=None):
+        """depth culling + gap filling + frames on host arrays (item_rgb: (n, 3) byte values); same dictionary keys as the tests' CPU checker.
+        pixel_rgb_in: (cells, 3) byte values, the grid's colours before the pass (read for border cells that carry an element)"""
         p = RcShadeParams(width, height, age_factor, zero, rnd, pmax)
         el = np.ascontiguousarray(pixel_element, dtype=np.int32); dep = np.ascontiguousarray(pixel_depth, dtype=np.float64)
         age = np.array(item_age, dtype=np.float64, copy=True)
@@ -311,6 +313,9 @@ class Renderer:
         rgb = np.ascontiguousarray(c[:, 0] | (c[:, 1] << 8) | (c[:, 2] << 16), dtype=np.uint32)
         cells = (width + 2) * (height + 2)
         prgb = np.zeros(cells, dtype=np.uint32); pprio = np.zeros(cells, dtype=np.int32)
+        if pixel_rgb_in is not None:
+            q = np.asarray(pixel_rgb_in, dtype=np.float64).reshape(cells, 3).astype(np.uint32)
+            prgb[:] = q[:, 0] | (q[:, 1] << 8) | (q[:, 2] << 16)
         hist = np.zeros(768, dtype=np.uint32); stats = np.zeros(3)
         frames = [np.zeros(width * height, dtype=np.uint32) for _ in range(3)]
         ip = C.POINTER(C.c_int32); up = C.POINTER(C.c_uint32)

@@ -61,3 +61,44 @@ def test_gpu_culling_filling_and_frames_bit_exact(golden_dir):
             check_shade(name, c, out)
     finally:
         r.close()
+
+
+@pytest.mark.gpu
+def test_gpu_elements_on_border_cells_match_the_cpu_restatement():
+    """Driver.initializeCache draws pixel positions from 0, so border cells of the grid can carry an element, and nothing
+    ever detaches them: depthCulling and fillGaps then see them as neighbours (their depth stays 1e13, their colour is the one
+    they were sampled with).  The whole-frame goldens (tests/golden/rc/frames_*, through Node) depend on this; here the GPU
+    pass is compared with the CPU restatement on random grids with many such cells."""
+    import ptr_amd
+    rng = np.random.default_rng(8804)
+    r = ptr_amd.Renderer(0)
+    try:
+        for w, h in ((37, 21), (64, 48), (5, 3)):
+            cells = (w + 2) * (h + 2)
+            n = 4 * w * h
+            el = np.full(cells, -1, dtype=np.int32)
+            grid = el.reshape(h + 2, w + 2)
+            take = rng.random((h + 2, w + 2)) < 0.3
+            take[0, :] = rng.random(w + 2) < 0.5; take[-1, :] = rng.random(w + 2) < 0.5
+            take[:, 0] = rng.random(h + 2) < 0.5; take[:, -1] = rng.random(h + 2) < 0.5
+            grid[take] = rng.choice(n, size=int(take.sum()), replace=False)
+            dep = np.full(cells, 1e6); dep[el >= 0] = rng.uniform(5, 60, int((el >= 0).sum()))
+            border = np.ones((h + 2, w + 2), dtype=bool); border[1:-1, 1:-1] = False
+            dep[border.ravel()] = 10000000000000.0                 # Pixel.js:8, never changed on the border
+            age = rng.integers(0, 60, n).astype(np.float64)
+            rgb = rng.integers(0, 256, (n, 3)).astype(np.float64)
+            prgb = np.zeros((cells, 3)); prgb[border.ravel()] = rng.integers(0, 256, (int(border.sum()), 3))
+            want = orc.rc_shade(w, h, el, dep, age, rgb, pixel_rgb_in=prgb)
+            got = r.rc_shade(w, h, el, dep, age, rgb, pixel_rgb_in=prgb)
+            inner = ~border.ravel()
+            assert np.array_equal(got["age"], want["age"])
+            assert np.array_equal(got["pixel_rgb"][inner], want["pixel_rgb"][inner])
+            assert np.array_equal(got["pixel_priority"][inner], want["pixel_priority"][inner])
+            assert np.array_equal(got["hist"], want["hist"]) and np.array_equal(got["stats"], want["stats"])
+            for key in ("color", "reprojection", "priority"):
+                assert np.array_equal(got[key], want[key]), key
+            # the border really mattered: masking its elements changes the result
+            el2 = el.copy(); el2[border.ravel()] = -1
+            assert not np.array_equal(orc.rc_shade(w, h, el2, dep, age, rgb)["pixel_priority"], want["pixel_priority"])
+    finally:
+        r.close()
