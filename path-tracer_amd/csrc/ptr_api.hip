@@ -275,6 +275,8 @@ int check_params(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frames)
     if (p->width < 1 || p->height < 1 || p->scan_height < 1)
         return fail(c, PTR_ERR_INVALID, "width, height and scan_height must be >= 1 (got %d, %d, %d)",
                     p->width, p->height, p->scan_height);
+    if (p->width >= (1 << 24))
+        return fail(c, PTR_ERR_INVALID, "width must be < 2^24 (got %d)", p->width);
     if (p->start_y < -(1 << 30) || p->start_y > (1 << 30))
         return fail(c, PTR_ERR_INVALID, "start_y out of range (%d)", p->start_y);
     if (n_frames < 1 || first_frame < 0 || first_frame + n_frames > c->n_frames)

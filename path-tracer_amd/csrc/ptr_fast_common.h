@@ -57,6 +57,9 @@ __device__ __forceinline__ bool lane_of(unsigned long long m) { return __builtin
 __device__ __forceinline__ float readlane_f(float v, int l)
 { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 
+// an unspecified (but, for the compiler, defined) value: for registers whose every use is masked until they are written
+__device__ __forceinline__ void any_value(float& v) { asm("" : "=v"(v)); }
+
 // max of two values that are known not to be NaN: fmaxf() spends an extra instruction per operand on quieting NaNs
 __device__ __forceinline__ float fmax_raw(float a, float b)
 {

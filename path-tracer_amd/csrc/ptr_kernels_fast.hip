@@ -38,6 +38,7 @@ struct Pixel {
 // state of a hit pixel during shading
 struct Shade {
     bool  valid;
+    unsigned long long valid_m; // ... as a lane mask
     int   self;                 // the element the pixel lies on, seen from outside (-1: none / seen from inside)
     F3    P, N;                 // hit point, normal (camera-relative)
     float t, eP, eN;
@@ -48,7 +49,7 @@ struct Shade {
     unsigned long long open_m, maybe_m, blocked_m;
 };
 
-template <bool HYBRID, bool DBG, int PPL>
+template <bool HYBRID, bool DBG, int PPL, bool GENERAL>
 __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(7))) render_fast_kernel(RenderArgs a)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -91,7 +92,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
         const float xx = fmaf((float)q.x + 0.5f, a.camf.sx, a.camf.ox);
         const float yy = fmaf((float)global_y(a, q.row) + 0.5f, a.camf.sy, a.camf.oy);
         F3 d;
-        if (a.cam.general) {
+        if constexpr (GENERAL) {          // a kernel of its own: as a run-time test the compiler computes both forms and selects
             d.x = fmaf(xx, a.camf.right[0], fmaf(yy, a.camf.up[0], a.camf.fwd[0]));
             d.y = fmaf(xx, a.camf.right[1], fmaf(yy, a.camf.up[1], a.camf.fwd[1]));
             d.z = fmaf(xx, a.camf.right[2], fmaf(yy, a.camf.up[2], a.camf.fwd[2]));
@@ -101,7 +102,9 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
         const float inv = rsq(dot3(d, d));
         q.d = F3{d.x * inv, d.y * inv, d.z * inv};
         q.tnear = 3.0e38f; q.t2 = 3.0e38f; q.etmax = 0.0f; q.idx = -1;
-        q.wl = F3{0.0f, 0.0f, 0.0f}; q.wcc = 1.0f; q.wr2 = 1.0f; q.wlnorm = 1.0f; q.web = 0.0f;
+        // the winner's record has no initial value: every use of it is masked by idx >= 0 (any bit pattern will do,
+        // and seven moves per pixel slot are saved)
+        any_value(q.wl.x); any_value(q.wl.y); any_value(q.wl.z); any_value(q.wcc); any_value(q.wr2); any_value(q.wlnorm); any_value(q.web);
     }
     {
         bool any_live = false;
@@ -124,7 +127,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
         const float xc = fmaf((float)(x0 + 4 * PPL), a.camf.sx, a.camf.ox);
         const float yc = fmaf((float)(global_y(a, row0) + PTR_TILE_H / 2), a.camf.sy, a.camf.oy);
         F3 dc;
-        if (a.cam.general) {
+        if constexpr (GENERAL) {
             dc.x = fmaf(xc, a.camf.right[0], fmaf(yc, a.camf.up[0], a.camf.fwd[0]));
             dc.y = fmaf(xc, a.camf.right[1], fmaf(yc, a.camf.up[1], a.camf.fwd[1]));
             dc.z = fmaf(xc, a.camf.right[2], fmaf(yc, a.camf.up[2], a.camf.fwd[2]));
@@ -138,7 +141,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
         const float sce = __builtin_amdgcn_sqrtf(fmaxf(cce, 0.0f));
         const float re = __builtin_amdgcn_sqrtf(fmaf(2.0f, g1.x, g1.z));
         const float K = fmaf(a.cull_cos, sce, -fmaf(a.cull_sin, re, 1e-5f * g1.w));   // 1e-5 |l|: rounding of all of this
-        cand = (unsigned)ballot((lane < n) & ((cce <= 0.0f) | (bc >= K)));
+        cand = (unsigned)(ballot(cce <= 0.0f) | ballot(bc >= K)) & ((1u << n) - 1u);
     }
 
     stamp(2);
@@ -184,13 +187,14 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
         // Two record buffers in SGPRs: the next candidate's record is requested before the current one is
         // used.  Record n exists (zero padding), so "no next candidate" needs no special case.
         unsigned todo = cand;
-        int i = todo ? __builtin_ctz(todo) : n;
-        P32Q A = load_p32(rec0 + 4 * i);
+        const unsigned stop = 1u << n;                 // record n: the zero padding
+        int i = __builtin_ctz(todo | stop);
+        P32Q A = load_p32(rec0 + 4u * (unsigned)i);
         while (todo) {
             todo &= todo - 1u;
-            const int inext = todo ? __builtin_ctz(todo) : n;
+            const int inext = __builtin_ctz(todo | stop);
             arrive(A);
-            const P32Q B = load_p32(rec0 + 4 * inext);
+            const P32Q B = load_p32(rec0 + 4u * (unsigned)inext);
             primary(A, i);
             arrive_after(B, px[PPL - 1].tnear);
             A = B;
@@ -209,9 +213,11 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
     for (int p = 0; p < PPL; p++) {
         Pixel& r = px[p];
         sh[p].valid = (r.idx >= 0) & r.live;
-        // nearest-vs-second ordering, far clip (t < 1e8, RayTracer.js:19,36)
-        unsure[p].add_mask(ballot((r.t2 - r.tnear <= 2.0f * r.etmax) & sh[p].valid), WHY_ORDER);
-        unsure[p].add_mask(ballot((r.tnear >= FAR_UNSURE) & sh[p].valid), WHY_FAR);
+        sh[p].valid_m = ballot(sh[p].valid);
+        // nearest-vs-second ordering, far clip (t < 1e8, RayTracer.js:19,36).  (A compare writes its lane mask directly;
+        // the ballot of `compare & bool` costs two more vector instructions.)
+        unsure[p].add_mask(ballot(r.t2 - r.tnear <= 2.0f * r.etmax) & sh[p].valid_m, WHY_ORDER);
+        unsure[p].add_mask(ballot(r.tnear >= FAR_UNSURE) & sh[p].valid_m, WHY_FAR);
         any_valid |= sh[p].valid;
     }
 
@@ -235,7 +241,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
             // root is taken in its cancellation-free form t = cc / (b + thc).
             const F3 lw = r.wl;
             const float cc_w = r.wcc, r2_w = r.wr2, lnorm_w = r.wlnorm, eb_w = r.web;
-            const float inv_r = rsq(fmaxf(r2_w, 1e-30f));
+            const float inv_r = rsq(fmax_raw(r2_w, 1e-30f));
             // half the error bound of disc' = r^2 - |l x d|^2: 10 eps r |l| + 2 eps r^2 (r from r^2: 2 more eps)
             const float hed_w = (10.5f * EPS) * (r2_w * inv_r) * lnorm_w + (2.5f * EPS) * r2_w;
             const F3 d = r.d;
@@ -250,10 +256,10 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
             const bool outside = cc_w > 0.0f;
             s.self = (outside & s.valid & self_ok) ? idx : -1;
             {
-                const unsigned long long vm = ballot(s.valid);
+                const unsigned long long vm = s.valid_m;
                 if (vm != 0ull) {                       // wave-uniform
                     const int first = __builtin_amdgcn_readlane(s.self, (int)__builtin_ctzll(vm));
-                    uni = uni & (ballot(s.valid & (s.self != first)) == 0ull) & (uni_self == -2 || uni_self == first);
+                    uni = uni & ((ballot(s.self != first) & vm) == 0ull) & (uni_self == -2 || uni_self == first);
                     uni_self = first;
                 }
             }
@@ -274,10 +280,10 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
         // distance of a shaded lane's P from it, plus the error of P and the 1e-4 bias (used by cone_prefilter).
         float pcx, pcy, pcz, prad;
         {
-            const unsigned long long v0 = ballot(sh[0].valid);
+            const unsigned long long v0 = sh[0].valid_m;
             const bool first = v0 != 0ull || PPL == 1;
             const Shade& sa = sh[first ? 0 : PPL - 1];
-            const int src = (int)__builtin_ctzll(first ? v0 : ballot(sa.valid));
+            const int src = (int)__builtin_ctzll(first ? v0 : sa.valid_m);
             pcx = readlane_f(sa.P.x, src); pcy = readlane_f(sa.P.y, src); pcz = readlane_f(sa.P.z, src);
             float dev = 0.0f;
 #pragma unroll
@@ -382,7 +388,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
             while (need) {
                 const int j = __builtin_ctz(need);
                 need &= need - 1u;
-                const P32H A = load_p32h(rec0 + 4 * j, pairs + j);
+                const P32H A = load_p32h(rec0 + 4u * (unsigned)j, pairs + j);
                 arrive(A);
                 shadow(A, j);
                 if (all_closed()) break;
@@ -393,16 +399,17 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
         const ConstM32 cm32 = (ConstM32)(uintptr_t)(block + a.off_m32);
         const ConstI32 clights = (ConstI32)(uintptr_t)(block + a.off_lights);
         for (int k = 0; k < nl; k++) {
-            const int i = clights[k];
-            // lights past the table's capacity share a record that never culls (thr < 0)
-            const int prow = k < PTR_MAX_PAIR_LIGHTS ? k : (n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS);
-            const ConstF4 pairs = pairs0 + (size_t)prow * (size_t)pair_stride(n);
-            const P32H pl = load_p32h(rec0 + 4 * i, pairs);
+            // (the mask tells the compiler that the index is small: 32-bit address arithmetic)
+            const unsigned i = (unsigned)clights[k] & 15u;
+            static_assert(PTR_FAST_MAX_SPHERES <= 16 && PTR_FAST_MAX_SPHERES <= PTR_MAX_PAIR_LIGHTS, "light k has pre-filter row k");
+            const unsigned prow = (unsigned)k * (unsigned)pair_stride(n);
+            const ConstF4 pairs = pairs0 + prow;
+            const P32H pl = load_p32h(rec0 + 4u * i, pairs);
             const F3 lpos{pl.g0.x, pl.g0.y, pl.g0.z};
             const float llnorm = pl.g1.w;
             const float ler = cm32[i].er, leg = cm32[i].eg, leb = cm32[i].eb, lemax = cm32[i].emax;
             // lane j's (light k, element j) pre-filter record, requested now for the cone test after the set-up
-            const float4 pq = reinterpret_cast<const float4*>(block + a.off_pairs)[(size_t)prow * (size_t)pair_stride(n) + (size_t)li];
+            const float4 pq = reinterpret_cast<const float4*>(block + a.off_pairs)[prow + (unsigned)li];
             const float4 cj = *reinterpret_cast<const float4*>(&gp32[li].lx);      // ... and element j's centre
 #pragma unroll
             for (int p = 0; p < PPL; p++) {
@@ -413,7 +420,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
                 s.eL = fmaf(fmaf(EPS, llnorm + s.t, s.eP), invl, 3.0f * EPS);   // |error of L|
                 s.ratio = dot3(s.N, s.L);
                 // lane masks: lanes still needing a verdict / inside a bound / blocked in float32
-                s.open_m = ballot((s.ratio > 0.0f) & s.valid);
+                s.open_m = ballot(s.ratio > 0.0f) & s.valid_m;
                 s.maybe_m = 0ull; s.blocked_m = 0ull;
             }
             if (!all_closed()) {
@@ -461,7 +468,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
             const float qr = __builtin_amdgcn_fractf(vr) - 0.5f, qg = __builtin_amdgcn_fractf(vg) - 0.5f,
                         qb = __builtin_amdgcn_fractf(vb) - 0.5f;
             const float nearest = fminf(fminf(fabsf(qr), fabsf(qg)), fabsf(qb));
-            unsure[p].add_mask(ballot((nearest <= band) & s.valid), WHY_ROUND);
+            unsure[p].add_mask(ballot(nearest <= band) & s.valid_m, WHY_ROUND);
             const uint32_t r8 = (uint32_t)(vr + 0.5f), g8 = (uint32_t)(vg + 0.5f), b8 = (uint32_t)(vb + 0.5f);
             packed[p] = s.valid ? (255u << 24) | (b8 << 16) | (g8 << 8) | r8 : bg_packed;
             if (a.out32f) { cr[p] = s.valid ? hr : bgr; cg[p] = s.valid ? hg : bgg; cb[p] = s.valid ? hb : bgb; }
@@ -483,11 +490,11 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
             // 0x2000: the first 6 pixels of the wave's first row carry the clocks spent in stages 0..5 instead
             if ((a.flags & 0x2000u) && p == 0 && lane < 6) packed[p] = (uint32_t)(ts[lane + 1] - ts[lane]);
         }
-        long long idx_out = (long long)a.width * r.row + r.x;
-        if (quirk) idx_out -= a.width;
-        if (idx_out >= 0) out8[idx_out] = packed[p];
+        // (width, rows < 2^24 and a call writes fewer than 2^32 pixels: checked by the host)
+        const unsigned pix = (unsigned)__umul24((unsigned)a.width, (unsigned)r.row) + (unsigned)r.x;
+        if (!quirk | (r.row > 0)) out8[quirk ? pix - (unsigned)a.width : pix] = packed[p];
         if (a.out32f) {
-            float4* o = reinterpret_cast<float4*>(a.out32f) + (frame * a.out_frame_stride + (uint64_t)a.width * r.row + r.x);
+            float4* o = reinterpret_cast<float4*>(a.out32f) + (frame * a.out_frame_stride + (uint64_t)pix);
             *o = make_float4(cr[p], cg[p], cb[p], 1.0f);
         }
         if constexpr (HYBRID) {
@@ -497,19 +504,25 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
                 const uint32_t sub = bid & (a.n_queues - 1u);       // n_queues is a power of two
                 const uint32_t q = atomicAdd(a.counter + sub * PTR_COUNTER_STRIDE, 1u);
                 if (q < a.queue_capacity)
-                    a.queue[(uint64_t)sub * a.queue_capacity + q] = (uint32_t)(frame * frame_px + (uint64_t)a.width * r.row + r.x);
+                    a.queue[(uint64_t)sub * a.queue_capacity + q] = (uint32_t)(frame * frame_px + (uint64_t)pix);
             }
         }
     }
 }
 
-template <bool HYBRID, bool DBG, int PPL>
-static hipError_t launch_variant(const RenderArgs& a, int n_frames, hipStream_t s)
+template <bool HYBRID, bool DBG, int PPL, bool GENERAL>
+static hipError_t launch_camera(const RenderArgs& a, int n_frames, hipStream_t s)
 {
     const int tw = PTR_TILE_W * PPL;
     dim3 grid((a.width + tw - 1) / tw, (a.scan_height + PTR_TILE_H - 1) / PTR_TILE_H, n_frames);
-    hipLaunchKernelGGL((render_fast_kernel<HYBRID, DBG, PPL>), grid, dim3(PTR_BLOCK), 0, s, a);
+    hipLaunchKernelGGL((render_fast_kernel<HYBRID, DBG, PPL, GENERAL>), grid, dim3(PTR_BLOCK), 0, s, a);
     return hipGetLastError();
+}
+
+template <bool HYBRID, bool DBG, int PPL>
+static hipError_t launch_variant(const RenderArgs& a, int n_frames, hipStream_t s)
+{
+    return a.cam.general ? launch_camera<HYBRID, DBG, PPL, true>(a, n_frames, s) : launch_camera<HYBRID, DBG, PPL, false>(a, n_frames, s);
 }
 
 int fast_kernel_rows_per_block() { return PTR_TILE_H; }
