@@ -116,7 +116,7 @@ void default_camera(ptr_camera& cam)
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct BlockLayout {
-    uint32_t off_g64, off_m64, off_p32, off_m32, off_lights, off_pairs;
+    uint32_t off_g64, off_m64, off_p32, off_m32, off_lights, off_pairs, off_lrec;
     size_t   bytes;
 };
 
@@ -136,6 +136,8 @@ BlockLayout block_layout(int n)
     o = align_up(o, 64);
     L.off_pairs = (uint32_t)o;
     o += sizeof(PairQ) * ((size_t)(n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS) + 1) * (size_t)pair_stride(n);
+    o = align_up(o, 64);
+    L.off_lrec = (uint32_t)o;   o += sizeof(LightRec) * ((size_t)n + 1);
     L.bytes = align_up(o, 256);
     return L;
 }
@@ -232,6 +234,12 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
     {
         const size_t row = (size_t)(n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS);
         for (int j = 0; j < pair_stride(n); j++) pairs[row * (size_t)pair_stride(n) + (size_t)j] = PairQ{0, 0, 0, -1.0f};
+    }
+    LightRec* lrec = reinterpret_cast<LightRec*>(dst + L.off_lrec);      // (the block is zeroed: record nl is the padding)
+    for (int k = 0; k < nl; k++) {
+        const SphereP32& p = p32[lights[k]];
+        const SphereM32& m = m32[lights[k]];
+        lrec[k] = LightRec{p.lx, p.ly, p.lz, p.lnorm, m.er, m.eg, m.eb, m.emax, lights[k], {0, 0, 0}};
     }
     for (int k = 0; k < 3; k++) {
         h->bg64[k] = bg[k];
@@ -330,7 +338,7 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
     a.frame_stride = c->frame_stride;
     {
         const BlockLayout L = block_layout(c->n_spheres);
-        a.off_p32 = L.off_p32; a.off_m32 = L.off_m32; a.off_lights = L.off_lights; a.off_pairs = L.off_pairs;
+        a.off_p32 = L.off_p32; a.off_m32 = L.off_m32; a.off_lights = L.off_lights; a.off_pairs = L.off_pairs; a.off_lrec = L.off_lrec;
         a.n = c->n_spheres;
     }
     a.first_frame = first_frame;

@@ -77,6 +77,10 @@ struct alignas(16) SphereM32 { float sr, sg, sb, scmax, er, eg, eb, emax; };
 // which the line through the light with direction L can come within r_j (+ shadow bias) of C_j.
 // A shadow ray towards light k can only hit element j if |L.a| + (error of L) >= thr.
 struct alignas(16) PairQ { float ax, ay, az, thr; };
+// What the few-sphere kernel needs of light k, at an address that does not depend on loaded data (the element record
+// behind lights[k] costs two dependent scalar loads): [n_lights + 1], the last record is zero padding.
+struct alignas(16) LightRec { float lx, ly, lz, lnorm; float er, eg, eb, emax; int32_t index; int32_t pad[3]; };
+static_assert(sizeof(LightRec) == 48, "LightRec layout");
 __host__ __device__ inline int pair_stride(int n) { return (n + 2 + 3) & ~3; }
 
 struct FrameView {
@@ -120,6 +124,7 @@ struct RenderArgs {
     const unsigned char* scenes;     // frame blocks, frame_stride bytes apart
     uint64_t  frame_stride;
     uint32_t  off_p32, off_m32, off_lights, off_pairs;   // byte offsets inside a frame block (same for every frame)
+    uint32_t  off_lrec;
     int32_t   n;                     // elements per frame
     int32_t   first_frame, n_frames;
     int32_t   width, height, start_y, scan_height;

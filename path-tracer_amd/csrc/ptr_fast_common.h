@@ -37,11 +37,17 @@ __device__ __forceinline__ P32H load_p32h(ConstF4 rec, ConstF4 pair) { return P3
 // hazard check stalls the wave right behind the load.
 // arrive_after() also takes a value the preceding compute produces, which pins the wait AFTER that
 // compute (an asm is otherwise free to float up to just behind the loads, which hides nothing).
+// light k's record (LightRec)
+struct LightQ { f4 g, e; int32_t index; };
+__device__ __forceinline__ LightQ load_light(ConstF4 rec)
+{ return LightQ{rec[0], rec[1], *reinterpret_cast<const volatile int32_t PTR_CONST*>(rec + 2)}; }
 #define PTR_F4_IN(v) "s"((v).x), "s"((v).y), "s"((v).z), "s"((v).w)
 __device__ __forceinline__ void arrive(const P32Q& q)
 { asm volatile("" ::PTR_F4_IN(q.g0), PTR_F4_IN(q.g1), PTR_F4_IN(q.g2)); }
 __device__ __forceinline__ void arrive_after(const P32Q& q, float dep)
 { asm volatile("" ::PTR_F4_IN(q.g0), PTR_F4_IN(q.g1), PTR_F4_IN(q.g2), "v"(dep)); }
+__device__ __forceinline__ void arrive(const LightQ& q)
+{ asm volatile("" ::PTR_F4_IN(q.g), PTR_F4_IN(q.e), "s"(q.index)); }
 __device__ __forceinline__ void arrive(const P32H& q)
 { asm volatile("" ::PTR_F4_IN(q.g0), PTR_F4_IN(q.g1), PTR_F4_IN(q.pa)); }
 __device__ __forceinline__ void arrive_after(const P32H& q, unsigned long long dep)
@@ -53,12 +59,20 @@ __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x);
 __device__ __forceinline__ unsigned long long ballot(bool c) { return __builtin_amdgcn_ballot_w64(c); }
 __device__ __forceinline__ bool lane_of(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
+// a per-lane 16-byte load that stays where it is written (the compiler otherwise sinks it next to its first use)
+__device__ __forceinline__ float4 load_f4(const volatile float4* p)
+{
+    const f4 v = *reinterpret_cast<const volatile f4*>(p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // lane `l`'s value of v as a wave-uniform value
 __device__ __forceinline__ float readlane_f(float v, int l)
 { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 
 // an unspecified (but, for the compiler, defined) value: for registers whose every use is masked until they are written
-__device__ __forceinline__ void any_value(float& v) { asm("" : "=v"(v)); }
+// (volatile: one register per use, not one shared value that then has to be copied)
+__device__ __forceinline__ void any_value(float& v) { asm volatile("" : "=v"(v)); }
 
 // max of two values that are known not to be NaN: fmaxf() spends an extra instruction per operand on quieting NaNs
 __device__ __forceinline__ float fmax_raw(float a, float b)

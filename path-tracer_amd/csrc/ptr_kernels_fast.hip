@@ -102,9 +102,6 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
         const float inv = rsq(dot3(d, d));
         q.d = F3{d.x * inv, d.y * inv, d.z * inv};
         q.tnear = 3.0e38f; q.t2 = 3.0e38f; q.etmax = 0.0f; q.idx = -1;
-        // the winner's record has no initial value: every use of it is masked by idx >= 0 (any bit pattern will do,
-        // and seven moves per pixel slot are saved)
-        any_value(q.wl.x); any_value(q.wl.y); any_value(q.wl.z); any_value(q.wcc); any_value(q.wr2); any_value(q.wlnorm); any_value(q.web);
     }
     {
         bool any_live = false;
@@ -159,6 +156,8 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
             any_m |= poss[p];
         }
         if (any_m == 0ull) return;                     // wave-uniform: ONE compare -> mask -> branch trip per sphere
+        const float ccf = q.g2.y;                      // 0.0f or 1.0f: compared as bits, on the scalar side
+        const bool cc_flag = __float_as_uint(ccf) != 0u;
 #pragma unroll
         for (int p = 0; p < PPL; p++) {
             Pixel& r = px[p];
@@ -168,7 +167,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
             const float m = fminf(b * q.g1.y, disc);   // hit <=> b >= 0 && disc >= 0 <=> m >= 0
             const unsigned long long hit_m = ballot(m >= 0.0f);
             unsure[p].add_mask(ballot(fabsf(m) <= q.g1.x) & poss_m, WHY_PRIMARY);
-            unsure[p].add_mask(q.g2.y != 0.0f ? hit_m : 0ull, WHY_CC);
+            unsure[p].add_mask(cc_flag ? hit_m : 0ull, WHY_CC);
             // Branch-free for the lanes that miss (they carry t = "never" and add no error): switching lanes off and on
             // costs more than the two selects.  Only the copy of a new leader's record is predicated.
             const bool hit = m >= 0.0f;
@@ -186,23 +185,31 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
     {
         // Two record buffers in SGPRs: the next candidate's record is requested before the current one is
         // used.  Record n exists (zero padding), so "no next candidate" needs no special case.
-        unsigned todo = cand;
-        const unsigned stop = 1u << n;                 // record n: the zero padding
-        int i = __builtin_ctz(todo | stop);
-        P32Q A = load_p32(rec0 + 4u * (unsigned)i);
-        while (todo) {
-            todo &= todo - 1u;
-            const int inext = __builtin_ctz(todo | stop);
-            arrive(A);
-            const P32Q B = load_p32(rec0 + 4u * (unsigned)inext);
-            primary(A, i);
-            arrive_after(B, px[PPL - 1].tnear);
-            A = B;
-            i = inext;
+        // the winner's record has no initial value: every use of it is masked by idx >= 0 (any bit pattern will do,
+        // and seven moves per pixel slot are saved)
+#pragma unroll
+        for (int p = 0; p < PPL; p++) {
+            Pixel& q = px[p];
+            any_value(q.wl.x); any_value(q.wl.y); any_value(q.wl.z); any_value(q.wcc); any_value(q.wr2); any_value(q.wlnorm); any_value(q.web);
         }
-        arrive(A);
+        if (cand != 0u) {
+            unsigned todo = cand;
+            const unsigned stop = 1u << n;             // record n: the zero padding
+            int i = __builtin_ctz(todo);
+            P32Q A = load_p32(rec0 + 4u * (unsigned)i);
+            do {
+                todo &= todo - 1u;
+                const int inext = __builtin_ctz(todo | stop);
+                arrive(A);
+                const P32Q B = load_p32(rec0 + 4u * (unsigned)inext);
+                primary(A, i);
+                arrive_after(B, px[PPL - 1].tnear);
+                A = B;
+                i = inext;
+            } while (todo);
+            arrive(A);
+        }
     }
-
     stamp(3);
     // miss: the background, bit-exact by construction (RayTracer.js:43-46)
     float cr[PPL], cg[PPL], cb[PPL];
@@ -212,7 +219,8 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
     for (int p = 0; p < PPL; p++) {
         Pixel& r = px[p];
-        sh[p].valid = (r.idx >= 0) & r.live;
+        // (lanes outside the image trace a ray like every other and are only kept from storing: `live` is not needed here)
+        sh[p].valid = r.idx >= 0;
         sh[p].valid_m = ballot(sh[p].valid);
         // nearest-vs-second ordering, far clip (t < 1e8, RayTracer.js:19,36).  (A compare writes its lane mask directly;
         // the ballot of `compare & bool` costs two more vector instructions.)
@@ -228,7 +236,18 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
         // P + 1e-4 N, at distance r + 1e-4 from the centre, so tca = l.L = -(r + 1e-4) N.L <= 0 whenever the light is
         // in front (N.L > 0), and should rounding lift tca to 0, d2 = |l|^2 - tca^2 > r^2 by 2e-4 r (Sphere.js:19-25).
         // The host vouches (self_skip) that float64 rounding at the scene's coordinates is far below that margin.
-        const bool self_ok = hdr->self_skip != 0u;
+        //
+        // Everything the light loop needs first is requested here, in one batch, and lands while the winner is refined:
+        // the header words, light 0's record (LightRec: its address does not depend on loaded data), lane j's pre-filter
+        // record for (light 0, element j) and element j's centre.
+        const ConstF4 lrec0 = (ConstF4)(uintptr_t)(block + a.off_lrec);
+        LightQ lq = load_light(lrec0);
+        const volatile uint32_t PTR_CONST* hw = (const volatile uint32_t PTR_CONST*)(uintptr_t)block;
+        const int nl = (int)hw[offsetof(FrameHeader, n_lights) / 4];
+        const bool self_ok = hw[offsetof(FrameHeader, self_skip) / 4] != 0u;
+        const volatile float4* lane_pairs = reinterpret_cast<const volatile float4*>(block + a.off_pairs) + li;
+        float4 pq = load_f4(lane_pairs);
+        const float4 cj = load_f4(reinterpret_cast<const volatile float4*>(&gp32[li].lx));
         int uni_self = -2;                              // >= 0: every shaded pixel of the wave lies on this element
         bool uni = true;
 #pragma unroll
@@ -254,15 +273,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
             const float bt = b_w + thc_w;
             const float rbt = rcp(bt);
             const bool outside = cc_w > 0.0f;
-            s.self = (outside & s.valid & self_ok) ? idx : -1;
-            {
-                const unsigned long long vm = s.valid_m;
-                if (vm != 0ull) {                       // wave-uniform
-                    const int first = __builtin_amdgcn_readlane(s.self, (int)__builtin_ctzll(vm));
-                    uni = uni & ((ballot(s.self != first) & vm) == 0ull) & (uni_self == -2 || uni_self == first);
-                    uni_self = first;
-                }
-            }
+            s.self = outside ? idx : -1;
             s.t = outside ? cc_w * rbt : bt;
             s.eP = outside ? s.t * fmaf(et_w, rbt, 4.0f * EPS) : fmaf(2.0f * EPS, s.t, et_w);   // |error of P|
 
@@ -274,6 +285,18 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
             s.N = F3{N.x * sg, N.y * sg, N.z * sg};
             s.eN = fmaf(s.eP + EPS * (lnorm_w + s.t), inv_r, 3.0f * EPS);   // |error of N|
             s.ar = 0.0f; s.ag = 0.0f; s.ab = 0.0f; s.wsum = 0.0f; s.eLmax = 0.0f;
+        }
+        // (after the arithmetic above: this is the first use of a word requested at the top)
+#pragma unroll
+        for (int p = 0; p < PPL; p++) {
+            Shade& s = sh[p];
+            s.self = (s.valid & self_ok) ? s.self : -1;
+            const unsigned long long vm = s.valid_m;
+            if (vm != 0ull) {                           // wave-uniform
+                const int first = __builtin_amdgcn_readlane(s.self, (int)__builtin_ctzll(vm));
+                uni = uni & ((ballot(s.self != first) & vm) == 0ull) & (uni_self == -2 || uni_self == first);
+                uni_self = first;
+            }
         }
         if (!uni) uni_self = -2;
         // The wave's shadow-ray origins lie in a ball: centre = the first shaded lane's hit point, radius = the largest
@@ -379,7 +402,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
             const F3 lcj{cj.x - pcx, cj.y - pcy, cj.z - pcz};          // lane j: element j's centre from the ball's centre
             const float lcn = __builtin_amdgcn_sqrtf(dot3(lcj, lcj)) * 1.000001f + 1e-6f;
             const float tca_up = fmaf(lcn, dmax, dot3(lcj, F3{ax, ay, az})) + prad * 1.000001f;
-            return (unsigned)ballot((fabsf(c) + dmax >= pq.w) & (tca_up >= 0.0f) & (lane < n));  // thr carries 8 more eps of slack
+            return (unsigned)(ballot(fabsf(c) + dmax >= pq.w) & ballot(tca_up >= 0.0f)) & ((1u << n) - 1u);  // thr carries 8 more eps of slack
         };
         // Phase 2: the full test for the occluders whose bit is set (next record requested before the current is used)
         auto shadow_bits = [&](ConstF4 pairs, unsigned need) {
@@ -395,22 +418,15 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
             }
         };
 
-        const int nl = hdr->n_lights;
-        const ConstM32 cm32 = (ConstM32)(uintptr_t)(block + a.off_m32);
-        const ConstI32 clights = (ConstI32)(uintptr_t)(block + a.off_lights);
+        static_assert(PTR_FAST_MAX_SPHERES <= 16 && PTR_FAST_MAX_SPHERES <= PTR_MAX_PAIR_LIGHTS, "light k has pre-filter row k");
         for (int k = 0; k < nl; k++) {
-            // (the mask tells the compiler that the index is small: 32-bit address arithmetic)
-            const unsigned i = (unsigned)clights[k] & 15u;
-            static_assert(PTR_FAST_MAX_SPHERES <= 16 && PTR_FAST_MAX_SPHERES <= PTR_MAX_PAIR_LIGHTS, "light k has pre-filter row k");
+            arrive(lq);
+            const unsigned i = (unsigned)lq.index & 15u;       // (the mask tells the compiler that the index is small)
             const unsigned prow = (unsigned)k * (unsigned)pair_stride(n);
             const ConstF4 pairs = pairs0 + prow;
-            const P32H pl = load_p32h(rec0 + 4u * i, pairs);
-            const F3 lpos{pl.g0.x, pl.g0.y, pl.g0.z};
-            const float llnorm = pl.g1.w;
-            const float ler = cm32[i].er, leg = cm32[i].eg, leb = cm32[i].eb, lemax = cm32[i].emax;
-            // lane j's (light k, element j) pre-filter record, requested now for the cone test after the set-up
-            const float4 pq = reinterpret_cast<const float4*>(block + a.off_pairs)[prow + (unsigned)li];
-            const float4 cj = *reinterpret_cast<const float4*>(&gp32[li].lx);      // ... and element j's centre
+            const F3 lpos{lq.g.x, lq.g.y, lq.g.z};
+            const float llnorm = lq.g.w;
+            const float ler = lq.e.x, leg = lq.e.y, leb = lq.e.z, lemax = lq.e.w;
 #pragma unroll
             for (int p = 0; p < PPL; p++) {
                 Shade& s = sh[p];
@@ -443,6 +459,9 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
                 s.wsum += lit ? lemax : 0.0f;
                 s.eLmax = fmax_raw(s.eLmax, lit ? s.eL : 0.0f);
             }
+            // the next light's record and pre-filter row (the tables end with a padding record / row)
+            lq = load_light(lrec0 + 3 * (k + 1));
+            pq = load_f4(lane_pairs + (prow + (unsigned)pair_stride(n)));
         }
 
         stamp(5);
