@@ -84,9 +84,11 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
         q.x = blockIdx.x * (PTR_TILE_W * PPL) + wave * (8 * PPL) + p * 8 + (lane & 7);
         q.row = blockIdx.y * PTR_TILE_H + (lane >> 3);
         q.live = (q.x < a.width) & (q.row < a.scan_height);
-        if (quirk & q.live & (q.row == 0)) {          // RayTracer.js:169: dropped row / untouched last row
-            out8[(uint64_t)a.width * (a.scan_height - 1) + q.x] = 0u;
-            q.live = a.out32f != nullptr;
+        if (quirk && blockIdx.y == 0) {               // wave-uniform; RayTracer.js:169: dropped row / untouched last row
+            if (q.live & (q.row == 0)) {
+                out8[(uint64_t)a.width * (a.scan_height - 1) + q.x] = 0u;
+                q.live = a.out32f != nullptr;
+            }
         }
         // camera ray (RayTracer.js:171-174)
         const float xx = fmaf((float)q.x + 0.5f, a.camf.sx, a.camf.ox);
@@ -248,8 +250,6 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
         const volatile float4* lane_pairs = reinterpret_cast<const volatile float4*>(block + a.off_pairs) + li;
         float4 pq = load_f4(lane_pairs);
         const float4 cj = load_f4(reinterpret_cast<const volatile float4*>(&gp32[li].lx));
-        int uni_self = -2;                              // >= 0: every shaded pixel of the wave lies on this element
-        bool uni = true;
 #pragma unroll
         for (int p = 0; p < PPL; p++) {
             Pixel& r = px[p];
@@ -288,17 +288,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
         }
         // (after the arithmetic above: this is the first use of a word requested at the top)
 #pragma unroll
-        for (int p = 0; p < PPL; p++) {
-            Shade& s = sh[p];
-            s.self = (s.valid & self_ok) ? s.self : -1;
-            const unsigned long long vm = s.valid_m;
-            if (vm != 0ull) {                           // wave-uniform
-                const int first = __builtin_amdgcn_readlane(s.self, (int)__builtin_ctzll(vm));
-                uni = uni & ((ballot(s.self != first) & vm) == 0ull) & (uni_self == -2 || uni_self == first);
-                uni_self = first;
-            }
-        }
-        if (!uni) uni_self = -2;
+        for (int p = 0; p < PPL; p++) sh[p].self = (sh[p].valid & self_ok) ? sh[p].self : -1;
         // The wave's shadow-ray origins lie in a ball: centre = the first shaded lane's hit point, radius = the largest
         // distance of a shaded lane's P from it, plus the error of P and the 1e-4 bias (used by cone_prefilter).
         float pcx, pcy, pcz, prad;
@@ -323,7 +313,6 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
         // ---- direct light + binary shadow (RayTracer.js:61-91) ---------------------------------
         // one shadow test of sphere record pj for every pixel slot
         auto shadow = [&](const P32H& pj, int j) {
-            if (j == uni_self) return;                 // the whole wave stands on element j
             if constexpr (DBG) dbg_pre_tests++;
             // Pre-filter: the shadow ray leaves (within the 1e-4 bias) along the line through the
             // light's centre, so it can only reach element j if that line does: |L.a| >= thr, with
@@ -338,12 +327,12 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
                 near_m |= pass_m[p];
             }
             if (near_m == 0ull) return;
-            if (uni_self == -2) {                      // mixed wave: lanes standing on j need no test of j
-                near_m = 0ull;
+            // lanes standing on j need no test of j (few records get this far: cheaper here than a wave-level
+            // "everybody stands on j" worked out once per wave)
+            near_m = 0ull;
 #pragma unroll
-                for (int p = 0; p < PPL; p++) near_m |= pass_m[p] & ~ballot(sh[p].self == j);
-                if (near_m == 0ull) return;
-            }
+            for (int p = 0; p < PPL; p++) near_m |= pass_m[p] & ~ballot(sh[p].self == j);
+            if (near_m == 0ull) return;
             if constexpr (DBG) dbg_full_tests++;
 #pragma unroll
             for (int p = 0; p < PPL; p++) {
@@ -442,7 +431,6 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
             if (!all_closed()) {
                 // every element but the light itself (RayTracer.js:76) and the one the whole wave stands on
                 unsigned need = cone_prefilter(pq, cj) & ~(1u << i);
-                if (uni_self >= 0) need &= ~(1u << uni_self);
                 shadow_bits(pairs, need);
             }
 #pragma unroll
@@ -499,11 +487,14 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
 
     stamp(6);
     // ---- stores ---------------------------------------------------------------------------------
-    const uint32_t bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    // (which lanes store is worked out again here rather than carried in a register through the whole kernel)
+    const int row_min = quirk ? 1 : 0;                  // PTR_QUIRK_ROW_SHIFT: row 0 has no destination, the others move up one row
+    const unsigned qshift = quirk ? (unsigned)a.width : 0u;
 #pragma unroll
     for (int p = 0; p < PPL; p++) {
         const Pixel& r = px[p];
-        if (!r.live) continue;
+        const bool in_img = (r.x < a.width) & (r.row < a.scan_height);
+        const bool st8 = in_img & (r.row >= row_min);
         if constexpr (DBG) {
             packed[p] = unsure[p].why() | (dbg_full_tests << 8) | (dbg_pre_tests << 16);
             // 0x2000: the first 6 pixels of the wave's first row carry the clocks spent in stages 0..5 instead
@@ -511,15 +502,20 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
         }
         // (width, rows < 2^24 and a call writes fewer than 2^32 pixels: checked by the host)
         const unsigned pix = (unsigned)__umul24((unsigned)a.width, (unsigned)r.row) + (unsigned)r.x;
-        if (!quirk | (r.row > 0)) out8[quirk ? pix - (unsigned)a.width : pix] = packed[p];
+        if (st8) out8[pix - qshift] = packed[p];
         if (a.out32f) {
-            float4* o = reinterpret_cast<float4*>(a.out32f) + (frame * a.out_frame_stride + (uint64_t)pix);
-            *o = make_float4(cr[p], cg[p], cb[p], 1.0f);
+            if (in_img) {
+                float4* o = reinterpret_cast<float4*>(a.out32f) + (frame * a.out_frame_stride + (uint64_t)pix);
+                *o = make_float4(cr[p], cg[p], cb[p], 1.0f);
+            }
         }
         if constexpr (HYBRID) {
-            if (unsure[p].any()) {
+            if (unsure[p].mask == 0ull) continue;      // wave-uniform: nearly every wave leaves here
+            if (unsure[p].any() & (st8 | (in_img & (a.out32f != nullptr)))) {
                 // one counter word would saturate (~88 returning atomics/us chip-wide): the queue is
                 // cut into n_queues sub-queues, each with its own counter line, chosen by workgroup
+                uint32_t bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+                asm volatile("" : "+s"(bid));           // keeps the address arithmetic below behind the branch above
                 const uint32_t sub = bid & (a.n_queues - 1u);       // n_queues is a power of two
                 const uint32_t q = atomicAdd(a.counter + sub * PTR_COUNTER_STRIDE, 1u);
                 if (q < a.queue_capacity)

@@ -1,7 +1,7 @@
 """Diagnostics (GPU) for the float32 kernel on the example scene at 1080p, from its debug build (PTR_DEBUG_REASONS):
   * shadow tests a wave runs (full tests in bits 8-15, pre-filter tests in bits 16-23 of every pixel);
   * shader clocks a wave spends per stage (debug flag 0x2000: lanes 0..5 of every wave's first row), under load
-    (whole frame) and with at most one wave per SIMD (a 16-row band: 240 waves on 1024 SIMDs = pure latency).
+    (whole frame) and with at most one wave per SIMD (an 8-row band: 120 waves on 1024 SIMDs = pure latency).
 Usage: python tools/diag_fast_counts.py"""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,8 +17,8 @@ DBG = ptr_amd.MODE_F32_ONLY | 0x8000
 
 
 def tiles(img, rows):
-    """one row of values per wave tile (8 wide x 16 tall): the tile's first pixel row"""
-    return img[: rows // 16 * 16].reshape(rows // 16, 16, w // 8, 8)[:, 0]
+    """one row of values per wave tile (16 wide x 8 tall, the two pixel slots side by side): the tile's first pixel row"""
+    return img[: rows // 8 * 8].reshape(rows // 8, 8, w // 16, 16)[:, 0]
 
 
 why = r.render(w, h, flags=DBG).reshape(h, w)
@@ -42,5 +42,5 @@ def stages(img, rows, label):
 
 stages(r.render(w, h, flags=DBG | 0x2000).reshape(h, w), h, "loaded (whole frame):")
 for y0 in (300, 700):
-    stages(r.render(w, h, start_y=y0, scan_height=16, flags=DBG | 0x2000).reshape(16, w), 16,
-           "one wave per SIMD at most, rows %d..%d:" % (y0, y0 + 15))
+    stages(r.render(w, h, start_y=y0, scan_height=8, flags=DBG | 0x2000).reshape(8, w), 8,
+           "one wave per SIMD at most, rows %d..%d:" % (y0, y0 + 7))
