@@ -74,6 +74,14 @@ __device__ __forceinline__ float readlane_f(float v, int l)
 // (volatile: one register per use, not one shared value that then has to be copied)
 __device__ __forceinline__ void any_value(float& v) { asm volatile("" : "=v"(v)); }
 
+// lane-wise m ? a : b for a lane mask m, as one v_cndmask
+__device__ __forceinline__ uint32_t select_u32(unsigned long long m, uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+
 // max of two values that are known not to be NaN: fmaxf() spends an extra instruction per operand on quieting NaNs
 __device__ __forceinline__ float fmax_raw(float a, float b)
 {

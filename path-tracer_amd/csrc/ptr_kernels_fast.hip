@@ -198,23 +198,29 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
             unsigned todo = cand;
             const unsigned stop = 1u << n;             // record n: the zero padding
             int i = __builtin_ctz(todo);
-            P32Q A = load_p32(rec0 + 4u * (unsigned)i);
-            do {
+            P32Q A = load_p32(rec0 + 4u * (unsigned)i), B;
+            // (two steps per trip, the buffers swapping roles: no record is copied from one set of SGPRs to the other)
+            auto step = [&](const P32Q& cur, P32Q& next) {
                 todo &= todo - 1u;
                 const int inext = __builtin_ctz(todo | stop);
-                arrive(A);
-                const P32Q B = load_p32(rec0 + 4u * (unsigned)inext);
-                primary(A, i);
-                arrive_after(B, px[PPL - 1].tnear);
-                A = B;
+                arrive(cur);
+                next = load_p32(rec0 + 4u * (unsigned)inext);
+                primary(cur, i);
+                arrive_after(next, px[PPL - 1].tnear);
                 i = inext;
-            } while (todo);
-            arrive(A);
+            };
+            for (;;) {
+                step(A, B);
+                if (!todo) break;
+                step(B, A);
+                if (!todo) break;
+            }
         }
     }
     stamp(3);
     // miss: the background, bit-exact by construction (RayTracer.js:43-46)
-    float cr[PPL], cg[PPL], cb[PPL];
+    float cr[PPL], cg[PPL], cb[PPL];           // shaded colour (lanes of shaded_m; the others take the background at the store)
+    unsigned long long shaded_m[PPL];
     uint32_t packed[PPL];
     Shade sh[PPL];
     bool any_valid = false;
@@ -454,7 +460,6 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
 
         stamp(5);
         // the background (RayTracer.js:43-46, bit-exact by construction) is read only here: four SGPRs fewer to carry
-        const float bgr = hdr->bg32[0], bgg = hdr->bg32[1], bgb = hdr->bg32[2];
         const uint32_t bg_packed = hdr->bg_packed;
         // the winners' materials, gathered only now (all requests first): surfaceColor * (sum over lights) + emission
         // (RayTracer.js:85-93)
@@ -477,12 +482,13 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
             const float nearest = fminf(fminf(fabsf(qr), fabsf(qg)), fabsf(qb));
             unsure[p].add_mask(ballot(nearest <= band) & s.valid_m, WHY_ROUND);
             const uint32_t r8 = (uint32_t)(vr + 0.5f), g8 = (uint32_t)(vg + 0.5f), b8 = (uint32_t)(vb + 0.5f);
-            packed[p] = s.valid ? (255u << 24) | (b8 << 16) | (g8 << 8) | r8 : bg_packed;
-            if (a.out32f) { cr[p] = s.valid ? hr : bgr; cg[p] = s.valid ? hg : bgg; cb[p] = s.valid ? hb : bgb; }
+            // (a select, spelled out: the compiler otherwise switches the unshaded lanes off around the conversion above)
+            packed[p] = select_u32(s.valid_m, (255u << 24) | (b8 << 16) | (g8 << 8) | r8, bg_packed);
+            cr[p] = hr; cg[p] = hg; cb[p] = hb; shaded_m[p] = s.valid_m;
         }
     } else {
 #pragma unroll
-        for (int p = 0; p < PPL; p++) { cr[p] = hdr->bg32[0]; cg[p] = hdr->bg32[1]; cb[p] = hdr->bg32[2]; packed[p] = hdr->bg_packed; }
+        for (int p = 0; p < PPL; p++) { cr[p] = 0.0f; cg[p] = 0.0f; cb[p] = 0.0f; shaded_m[p] = 0ull; packed[p] = hdr->bg_packed; }
     }
 
     stamp(6);
@@ -506,7 +512,8 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
         if (a.out32f) {
             if (in_img) {
                 float4* o = reinterpret_cast<float4*>(a.out32f) + (frame * a.out_frame_stride + (uint64_t)pix);
-                *o = make_float4(cr[p], cg[p], cb[p], 1.0f);
+                const bool shaded = lane_of(shaded_m[p]);
+                *o = make_float4(shaded ? cr[p] : hdr->bg32[0], shaded ? cg[p] : hdr->bg32[1], shaded ? cb[p] : hdr->bg32[2], 1.0f);
             }
         }
         if constexpr (HYBRID) {
