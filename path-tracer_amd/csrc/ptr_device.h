@@ -14,6 +14,7 @@
 #define PTR_TILE_W 32         // workgroup tile: 4 waves side by side, each an 8x8 pixel tile
 #define PTR_TILE_H 8
 #define PTR_BLOCK  256
+#define PTR_FAST_BLOCK 64     // few-sphere kernel: one wave per workgroup (no LDS, no barrier: a wave then starts wherever a slot is free)
 #define PTR_FAST_PPL 2            // pixels per lane in the float32 kernel (wave tile 16 x 8: the slots side by side)
 #define PTR_MAX_QUEUES 1024       // sub-queues of the hybrid mode's re-trace queue
 #define PTR_MAX_PAIR_LIGHTS 64     // lights with a shadow pre-filter table (more lights: no culling for them)

@@ -50,7 +50,7 @@ struct Shade {
 };
 
 template <bool HYBRID, bool DBG, int PPL, bool GENERAL>
-__global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(7))) render_fast_kernel(RenderArgs a)
+__global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_per_eu(7))) render_fast_kernel(RenderArgs a)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int frame = blockIdx.z;
@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
     for (int p = 0; p < PPL; p++) {
         Pixel& q = px[p];
-        q.x = blockIdx.x * (PTR_TILE_W * PPL) + wave * (8 * PPL) + p * 8 + (lane & 7);
+        q.x = blockIdx.x * (PTR_FAST_BLOCK / 64 * 8 * PPL) + wave * (8 * PPL) + p * 8 + (lane & 7);
         q.row = blockIdx.y * PTR_TILE_H + (lane >> 3);
         q.live = (q.x < a.width) & (q.row < a.scan_height);
         if (quirk && blockIdx.y == 0) {               // wave-uniform; RayTracer.js:169: dropped row / untouched last row
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
     // for every pixel, not an unsure one); the loop below then visits the set bits only.
     unsigned cand = (1u << n) - 1u;                    // n <= PTR_FAST_MAX_SPHERES
     if (a.cull_on) {
-        const int x0 = blockIdx.x * (PTR_TILE_W * PPL) + wave * (8 * PPL), row0 = blockIdx.y * PTR_TILE_H;
+        const int x0 = blockIdx.x * (PTR_FAST_BLOCK / 64 * 8 * PPL) + wave * (8 * PPL), row0 = blockIdx.y * PTR_TILE_H;
         const float xc = fmaf((float)(x0 + 4 * PPL), a.camf.sx, a.camf.ox);
         const float yc = fmaf((float)(global_y(a, row0) + PTR_TILE_H / 2), a.camf.sy, a.camf.oy);
         F3 dc;
@@ -535,9 +535,9 @@ __global__ void __launch_bounds__(PTR_BLOCK) __attribute__((amdgpu_waves_per_eu(
 template <bool HYBRID, bool DBG, int PPL, bool GENERAL>
 static hipError_t launch_camera(const RenderArgs& a, int n_frames, hipStream_t s)
 {
-    const int tw = PTR_TILE_W * PPL;
+    const int tw = PTR_FAST_BLOCK / 64 * 8 * PPL;
     dim3 grid((a.width + tw - 1) / tw, (a.scan_height + PTR_TILE_H - 1) / PTR_TILE_H, n_frames);
-    hipLaunchKernelGGL((render_fast_kernel<HYBRID, DBG, PPL, GENERAL>), grid, dim3(PTR_BLOCK), 0, s, a);
+    hipLaunchKernelGGL((render_fast_kernel<HYBRID, DBG, PPL, GENERAL>), grid, dim3(PTR_FAST_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 
@@ -548,7 +548,7 @@ static hipError_t launch_variant(const RenderArgs& a, int n_frames, hipStream_t 
 }
 
 int fast_kernel_rows_per_block() { return PTR_TILE_H; }
-int fast_kernel_cols_per_block() { return PTR_TILE_W * PTR_FAST_PPL; }
+int fast_kernel_cols_per_block() { return PTR_FAST_BLOCK / 64 * 8 * PTR_FAST_PPL; }
 
 hipError_t launch_render_fast(const RenderArgs& a, int n_frames, bool hybrid, hipStream_t s)
 {
