@@ -24,11 +24,20 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef const volatile f4 PTR_CONST* ConstF4;      // a SphereP32 record = 4 x f4
 
 // the 12 leading floats of a SphereP32 record (see ptr_device.h for the field names)
+typedef float f8 __attribute__((ext_vector_type(8)));
+// 8 floats by one s_load_dwordx8 (the record tables are 32-byte aligned)
+__device__ __forceinline__ void load_f8(ConstF4 rec, f4& lo, f4& hi)
+{
+    const f8 v = *reinterpret_cast<const volatile f8 PTR_CONST*>(rec);
+    lo = f4{v[0], v[1], v[2], v[3]};
+    hi = f4{v[4], v[5], v[6], v[7]};
+}
 struct P32Q { f4 g0, g1, g2; };
-__device__ __forceinline__ P32Q load_p32(ConstF4 rec) { return P32Q{rec[0], rec[1], rec[2]}; }
+__device__ __forceinline__ P32Q load_p32(ConstF4 rec) { P32Q q; load_f8(rec, q.g0, q.g1); q.g2 = rec[2]; return q; }
+struct P32G { f4 g0, g1; };
 // the 8 leading floats (shadow test) + the (light, element) pre-filter record
 struct P32H { f4 g0, g1, pa; };
-__device__ __forceinline__ P32H load_p32h(ConstF4 rec, ConstF4 pair) { return P32H{rec[0], rec[1], pair[0]}; }
+__device__ __forceinline__ P32H load_p32h(ConstF4 rec, ConstF4 pair) { P32H q; load_f8(rec, q.g0, q.g1); q.pa = pair[0]; return q; }
 // Scalar loads return out of order, so the only wait is "all of them": make the wave wait for the
 // record it is about to use BEFORE it requests the next one.  arrive() is an empty asm that
 // consumes every word of the record: that forces the wait here, and it keeps words the compute
@@ -37,15 +46,21 @@ __device__ __forceinline__ P32H load_p32h(ConstF4 rec, ConstF4 pair) { return P3
 // hazard check stalls the wave right behind the load.
 // arrive_after() also takes a value the preceding compute produces, which pins the wait AFTER that
 // compute (an asm is otherwise free to float up to just behind the loads, which hides nothing).
+// the 8 leading floats alone
+__device__ __forceinline__ P32G load_p32g(ConstF4 rec) { P32G q; load_f8(rec, q.g0, q.g1); return q; }
 // light k's record (LightRec)
 struct LightQ { f4 g, e; int32_t index; };
 __device__ __forceinline__ LightQ load_light(ConstF4 rec)
-{ return LightQ{rec[0], rec[1], *reinterpret_cast<const volatile int32_t PTR_CONST*>(rec + 2)}; }
+{ LightQ q; load_f8(rec, q.g, q.e); q.index = *reinterpret_cast<const volatile int32_t PTR_CONST*>(rec + 2); return q; }
 #define PTR_F4_IN(v) "s"((v).x), "s"((v).y), "s"((v).z), "s"((v).w)
 __device__ __forceinline__ void arrive(const P32Q& q)
 { asm volatile("" ::PTR_F4_IN(q.g0), PTR_F4_IN(q.g1), PTR_F4_IN(q.g2)); }
 __device__ __forceinline__ void arrive_after(const P32Q& q, float dep)
 { asm volatile("" ::PTR_F4_IN(q.g0), PTR_F4_IN(q.g1), PTR_F4_IN(q.g2), "v"(dep)); }
+__device__ __forceinline__ void arrive(const P32G& q)
+{ asm volatile("" ::PTR_F4_IN(q.g0), PTR_F4_IN(q.g1)); }
+__device__ __forceinline__ void arrive(const f4& q)
+{ asm volatile("" ::PTR_F4_IN(q)); }
 __device__ __forceinline__ void arrive(const LightQ& q)
 { asm volatile("" ::PTR_F4_IN(q.g), PTR_F4_IN(q.e), "s"(q.index)); }
 __device__ __forceinline__ void arrive(const P32H& q)

@@ -191,10 +191,9 @@ __device__ __forceinline__ bool any_lane_x(bool c) { return ballot(c) != 0ull; }
 __device__ V<float> trace_ext_f32(const unsigned char* block, const RenderArgs& a, V<float> o0, V<float> d0, int max_depth)
 {
     const ConstHeader hdr = (ConstHeader)(uintptr_t)block;
-    const ConstRec rec0 = (ConstRec)(uintptr_t)(block + a.off_p32);
-    const ConstRec pairs0 = (ConstRec)(uintptr_t)(block + a.off_pairs);
-    const ConstM32 cm32 = (ConstM32)(uintptr_t)(block + a.off_m32);
-    const ConstI32 clights = (ConstI32)(uintptr_t)(block + a.off_lights);
+    const ConstF4 recv0 = (ConstF4)(uintptr_t)(block + a.off_p32);      // the same table through loads that stay where they are written
+    const ConstF4 pairv0 = (ConstF4)(uintptr_t)(block + a.off_pairs);
+    const ConstF4 lrec0 = (ConstF4)(uintptr_t)(block + a.off_lrec);
     const SphereP32* gp32 = reinterpret_cast<const SphereP32*>(block + a.off_p32);
     const SphereM32* gm32 = reinterpret_cast<const SphereM32*>(block + a.off_m32);
     const int n = a.n, nl = hdr->n_lights;
@@ -215,21 +214,34 @@ __device__ V<float> trace_ext_f32(const unsigned char* block, const RenderArgs& 
         // nearest hit (RayTracer.js:26-41)
         float tnear = (float)PTR_INFINITY;
         int e = -1;
-        for (int i = 0; i < n; i++) {
-            const f4 g0 = rec0[4 * (size_t)i];
-            const float r2 = rec0[4 * (size_t)i + 1].z;
-            const float lx = g0.x - r.o.x, ly = g0.y - r.o.y, lz = g0.z - r.o.z;
-            const float b = fmaf(lz, r.d.z, fmaf(ly, r.d.y, lx * r.d.x));
-            const float ll = fmaf(lz, lz, fmaf(ly, ly, lx * lx));
-            const float disc = fmaf(b, b, r2 - ll);                       // radius2 - d2 (Sphere.js:21-27)
-            const bool hit = (b >= 0.0f) & (disc >= 0.0f);
-            if (any_lane_x(hit)) {
-                const float thc = disc * rsq(fmaxf(disc, 1e-30f));
-                float t = b - thc;
-                t = t < 0.0f ? b + thc : t;                               // RayTracer.js:32-34
-                const bool nearer = hit & (t < tnear);
-                tnear = nearer ? t : tnear;
-                e = nearer ? i : e;
+        {
+            // Two record buffers in SGPRs that swap roles: record i + 1 is requested before record i is used (the table
+            // ends with zero records, so the look-ahead needs no special case), and hit / miss is decided on lane masks.
+            auto test = [&](const P32G& q, int i) {
+                const float lx = q.g0.x - r.o.x, ly = q.g0.y - r.o.y, lz = q.g0.z - r.o.z;
+                const float b = fmaf(lz, r.d.z, fmaf(ly, r.d.y, lx * r.d.x));
+                const float ll = fmaf(lz, lz, fmaf(ly, ly, lx * lx));
+                const float disc = fmaf(b, b, q.g1.z - ll);                   // radius2 - d2 (Sphere.js:21-27)
+                const unsigned long long hit_m = ballot(b >= 0.0f) & ballot(disc >= 0.0f);
+                if (hit_m != 0ull) {
+                    const float thc = disc * rsq(fmax_raw(disc, 1e-30f));
+                    float t = b - thc;
+                    t = t < 0.0f ? b + thc : t;                               // RayTracer.js:32-34
+                    const bool nearer = lane_of(hit_m) & (t < tnear);
+                    tnear = nearer ? t : tnear;
+                    e = nearer ? i : e;
+                }
+            };
+            if (n > 0) {
+                ConstF4 rp = recv0;
+                P32G A = load_p32g(rp), B;
+                int i = 0;
+                for (;;) {
+                    rp += 4; arrive(A); B = load_p32g(rp); test(A, i);
+                    if (++i >= n) break;
+                    rp += 4; arrive(B); A = load_p32g(rp); test(B, i);
+                    if (++i >= n) break;
+                }
             }
         }
         if (e < 0) {
@@ -282,34 +294,48 @@ __device__ V<float> trace_ext_f32(const unsigned char* block, const RenderArgs& 
             // the reference's direct lighting (RayTracer.js:60-91)
             const float sox = fmaf(N.x, BIAS, P.x), soy = fmaf(N.y, BIAS, P.y), soz = fmaf(N.z, BIAS, P.z);
             float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+            LightQ lq = load_light(lrec0);                                   // LightRec: light kk at a data-independent address
             for (int kk = 0; kk < nl; kk++) {
-                const int i = clights[kk];
-                const f4 lg = rec0[4 * (size_t)i];
+                arrive(lq);
+                const int i = lq.index;
+                const float lgx = lq.g.x, lgy = lq.g.y, lgz = lq.g.z, ler = lq.e.x, leg = lq.e.y, leb = lq.e.z;
+                lq = load_light(lrec0 + 3u * (unsigned)(kk + 1));            // (the table ends with a padding record)
                 const int prow = kk < PTR_MAX_PAIR_LIGHTS ? kk : (n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS);
-                const ConstRec pairs = pairs0 + (size_t)prow * (size_t)pair_stride(n);
-                float Lx = lg.x - P.x, Ly = lg.y - P.y, Lz = lg.z - P.z;
+                const ConstF4 pairs = pairv0 + (unsigned)prow * (unsigned)pair_stride(n);
+                float Lx = lgx - P.x, Ly = lgy - P.y, Lz = lgz - P.z;
                 const float invl = rsq(fmaf(Lz, Lz, fmaf(Ly, Ly, Lx * Lx)));
                 Lx *= invl; Ly *= invl; Lz *= invl;
                 const float ratio = fmaf(N.z, Lz, fmaf(N.y, Ly, N.x * Lx));
-                bool open = ratio > 0.0f;                                 // max(0, N.L) = 0: the term vanishes either way
-                for (int j = 0; j < n; j++) {
-                    if (!any_lane_x(open)) break;
-                    if (j == i) continue;                                 // RayTracer.js:76
-                    const f4 pq = pairs[j];
-                    const float c = fmaf(pq.z, Lz, fmaf(pq.y, Ly, pq.x * Lx));
-                    if (!any_lane_x(open & (fabsf(c) + 1e-5f >= pq.w))) continue;
-                    const f4 g0 = rec0[4 * (size_t)j];
-                    const float r2 = rec0[4 * (size_t)j + 1].z;
-                    const float lx = g0.x - sox, ly = g0.y - soy, lz = g0.z - soz;
-                    const float b = fmaf(lz, Lz, fmaf(ly, Ly, lx * Lx));
-                    const float ll = fmaf(lz, lz, fmaf(ly, ly, lx * lx));
-                    const float disc = fmaf(b, b, r2 - ll);
-                    open = open & !((b >= 0.0f) & (disc >= 0.0f));        // any hit blocks; distance ignored (F7)
+                // lanes that still need a verdict (max(0, N.L) = 0: the term vanishes either way), as a lane mask
+                unsigned long long open_m = ballot(ratio > 0.0f);
+                if (open_m != 0ull && n > 0) {
+                    auto occluder = [&](const f4 pq, int j) {
+                        if (j == i) return;                                   // RayTracer.js:76
+                        const float c = fmaf(pq.z, Lz, fmaf(pq.y, Ly, pq.x * Lx));
+                        if ((ballot(fabsf(c) + 1e-5f >= pq.w) & open_m) == 0ull) return;
+                        const P32G q = load_p32g(recv0 + 4u * (unsigned)j);
+                        arrive(q);
+                        const float lx = q.g0.x - sox, ly = q.g0.y - soy, lz = q.g0.z - soz;
+                        const float b = fmaf(lz, Lz, fmaf(ly, Ly, lx * Lx));
+                        const float ll = fmaf(lz, lz, fmaf(ly, ly, lx * lx));
+                        const float disc = fmaf(b, b, q.g1.z - ll);
+                        open_m &= ~(ballot(b >= 0.0f) & ballot(disc >= 0.0f));   // any hit blocks; distance ignored (F7)
+                    };
+                    // pre-filter records one ahead, in two buffers that swap roles (rows are padded past n)
+                    ConstF4 pp = pairs;
+                    f4 A = *pp, B;
+                    int j = 0;
+                    for (;;) {
+                        ++pp; arrive(A); B = *pp; occluder(A, j);
+                        if (++j >= n || open_m == 0ull) break;
+                        ++pp; arrive(B); A = *pp; occluder(B, j);
+                        if (++j >= n || open_m == 0ull) break;
+                    }
                 }
-                const float lit = open ? ratio : 0.0f;
-                dx = fmaf(m.sr * cm32[i].er, lit, dx);
-                dy = fmaf(m.sg * cm32[i].eg, lit, dy);
-                dz = fmaf(m.sb * cm32[i].eb, lit, dz);
+                const float lit = lane_of(open_m) ? ratio : 0.0f;
+                dx = fmaf(m.sr * ler, lit, dx);
+                dy = fmaf(m.sg * leg, lit, dy);
+                dz = fmaf(m.sb * leb, lit, dz);
             }
             ax = fmaf(r.w.x, dx, ax); ay = fmaf(r.w.y, dy, ay); az = fmaf(r.w.z, dz, az);
         }

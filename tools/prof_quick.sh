@@ -16,7 +16,7 @@ agg = collections.defaultdict(list)
 for f in glob.glob(os.path.join(sys.argv[1], "pmc", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "ptr::render" not in k or int(r["Grid_Size"]) < 10_000_000: continue
+        if "ptr::" not in k or int(r["Grid_Size"]) < 10_000_000: continue
         agg[(k.split("(")[0][:40], r["Counter_Name"])].append(float(r["Counter_Value"]))
 ks = sorted({k for k, _ in agg})
 for k in ks:
