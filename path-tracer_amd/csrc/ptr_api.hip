@@ -116,7 +116,7 @@ void default_camera(ptr_camera& cam)
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct BlockLayout {
-    uint32_t off_g64, off_m64, off_p32, off_m32, off_lights, off_pairs, off_lrec;
+    uint32_t off_g64, off_m64, off_p32, off_m32, off_lights, off_pairs, off_lrec, off_cull;
     size_t   bytes;
 };
 
@@ -138,6 +138,8 @@ BlockLayout block_layout(int n)
     o += sizeof(PairQ) * ((size_t)(n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS) + 1) * (size_t)pair_stride(n);
     o = align_up(o, 64);
     L.off_lrec = (uint32_t)o;   o += sizeof(LightRec) * ((size_t)n + 1);
+    o = align_up(o, 64);
+    L.off_cull = (uint32_t)o;   o += sizeof(CullRec) * ((size_t)n + 1);
     L.bytes = align_up(o, 256);
     return L;
 }
@@ -234,6 +236,17 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
     {
         const size_t row = (size_t)(n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS);
         for (int j = 0; j < pair_stride(n); j++) pairs[row * (size_t)pair_stride(n) + (size_t)j] = PairQ{0, 0, 0, -1.0f};
+    }
+    CullRec* cull = reinterpret_cast<CullRec*>(dst + L.off_cull);        // (record n: zeros, read by the lanes past n)
+    for (int i = 0; i < n; i++) {
+        const SphereP32& p = p32[i];
+        // from the ROUNDED record values, the ones the kernel's hit test works with
+        const double cce = (double)p.cc - 2.0 * (double)p.md, re2 = (double)p.r2 + 2.0 * (double)p.md;
+        float s = -3.0e38f, re = (float)std::sqrt(re2);
+        if (cce > 0 && std::isfinite(cce)) { s = (float)std::sqrt(cce); if ((double)s * (double)s > cce) s = std::nextafterf(s, -INFINITY); }
+        if ((double)re * (double)re < re2) re = std::nextafterf(re, INFINITY);
+        if (!std::isfinite(re2)) s = -3.0e38f, re = 0.0f;
+        cull[i] = CullRec{p.lx, p.ly, p.lz, s, re, 1e-5f * p.lnorm, 0.0f, 0.0f};
     }
     LightRec* lrec = reinterpret_cast<LightRec*>(dst + L.off_lrec);      // (the block is zeroed: record nl is the padding)
     for (int k = 0; k < nl; k++) {
@@ -338,7 +351,7 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
     a.frame_stride = c->frame_stride;
     {
         const BlockLayout L = block_layout(c->n_spheres);
-        a.off_p32 = L.off_p32; a.off_m32 = L.off_m32; a.off_lights = L.off_lights; a.off_pairs = L.off_pairs; a.off_lrec = L.off_lrec;
+        a.off_p32 = L.off_p32; a.off_m32 = L.off_m32; a.off_lights = L.off_lights; a.off_pairs = L.off_pairs; a.off_lrec = L.off_lrec; a.off_cull = L.off_cull;
         a.n = c->n_spheres;
     }
     a.first_frame = first_frame;

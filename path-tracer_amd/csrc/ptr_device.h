@@ -82,6 +82,12 @@ struct alignas(16) PairQ { float ax, ay, az, thr; };
 // behind lights[k] costs two dependent scalar loads): [n_lights + 1], the last record is zero padding.
 struct alignas(16) LightRec { float lx, ly, lz, lnorm; float er, eg, eb, emax; int32_t index; int32_t pad[3]; };
 static_assert(sizeof(LightRec) == 48, "LightRec layout");
+// Tile culling of the few-sphere kernel, read by lane i for sphere i: a ray of a cone (axis dc, half-angle T) around the
+// wave tile's centre ray can reach sphere i, or the error band of its float32 hit test, only if
+//   l.dc >= cos(T) s - (sin(T) re + c),   s = sqrt(max(|l|^2 - r^2 - 2 md, 0)) rounded down (-3e38 when the origin is inside
+// the enlarged sphere: always a candidate), re = sqrt(r^2 + 2 md) rounded up, c = 1e-5 |l| (rounding of all of this).
+struct alignas(16) CullRec { float lx, ly, lz, s; float re, c, pad0, pad1; };
+static_assert(sizeof(CullRec) == 32, "CullRec layout");
 __host__ __device__ inline int pair_stride(int n) { return (n + 2 + 3) & ~3; }
 
 struct FrameView {
@@ -125,7 +131,7 @@ struct RenderArgs {
     const unsigned char* scenes;     // frame blocks, frame_stride bytes apart
     uint64_t  frame_stride;
     uint32_t  off_p32, off_m32, off_lights, off_pairs;   // byte offsets inside a frame block (same for every frame)
-    uint32_t  off_lrec;
+    uint32_t  off_lrec, off_cull;
     int32_t   n;                     // elements per frame
     int32_t   first_frame, n_frames;
     int32_t   width, height, start_y, scan_height;

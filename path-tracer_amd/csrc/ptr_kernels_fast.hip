@@ -68,8 +68,9 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
 
     // lane i's view of sphere record i for the culling step below, requested first: the latency passes during set-up
     const int li = lane < n ? lane : 0;                // record 0 exists even in an empty scene (zero padding)
-    const float4 cull_g0 = *reinterpret_cast<const float4*>(&gp32[li].lx);   // lx ly lz cc
-    const float4 cull_g1 = *reinterpret_cast<const float4*>(&gp32[li].md);   // md kb r2 lnorm
+    const CullRec* gcull = reinterpret_cast<const CullRec*>(block + a.off_cull);
+    const float4 cull_g0 = *reinterpret_cast<const float4*>(&gcull[li].lx);   // lx ly lz s
+    const float2 cull_g1 = *reinterpret_cast<const float2*>(&gcull[li].re);   // re c
 
     // ---- this lane's pixels: an (8*PPL) x 8 tile per wave (the pixel slots side by side: a tile never straddles two 8-row strips), (32*PPL) x 8 per workgroup ------------
     Pixel px[PPL];
@@ -84,12 +85,6 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
         q.x = blockIdx.x * (PTR_FAST_BLOCK / 64 * 8 * PPL) + wave * (8 * PPL) + p * 8 + (lane & 7);
         q.row = blockIdx.y * PTR_TILE_H + (lane >> 3);
         q.live = (q.x < a.width) & (q.row < a.scan_height);
-        if (quirk && blockIdx.y == 0) {               // wave-uniform; RayTracer.js:169: dropped row / untouched last row
-            if (q.live & (q.row == 0)) {
-                out8[(uint64_t)a.width * (a.scan_height - 1) + q.x] = 0u;
-                q.live = a.out32f != nullptr;
-            }
-        }
         // camera ray (RayTracer.js:171-174)
         const float xx = fmaf((float)q.x + 0.5f, a.camf.sx, a.camf.ox);
         const float yy = fmaf((float)global_y(a, q.row) + 0.5f, a.camf.sy, a.camf.oy);
@@ -111,6 +106,14 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
         for (int p = 0; p < PPL; p++) any_live |= px[p].live;
         if (ballot(any_live) == 0ull) return;          // wave-uniform exit: the whole wave is outside
     }
+    if (quirk && blockIdx.y == 0) {
+        // PTR_QUIRK_ROW_SHIFT (RayTracer.js:169): the last row of the band is never written by a pixel; the waves of the
+        // first tile row clear it.  (A wave-uniform branch that the other waves jump over; the empty asm keeps it one.)
+        asm volatile("");
+#pragma unroll
+        for (int p = 0; p < PPL; p++)
+            if (px[p].live & (px[p].row == 0)) out8[(uint64_t)a.width * (a.scan_height - 1) + px[p].x] = 0u;
+    }
 
     stamp(1);
     // ---- which spheres can a ray of this wave reach at all? ---------------------------------------
@@ -118,8 +121,9 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
     // block's centre ray dc (half-angle bound from the host, cull_sin / cull_cos).  A ray of the cone can
     // only hit sphere i if the angle between dc and l_i is at most that half-angle plus the sphere's own
     // angular radius asin(r / |l|):  l.dc >= cos(T) sqrt(cc) - sin(T) r.  Lane i evaluates this for sphere
-    // i (radius enlarged by the error band of the float32 hit test, so a culled sphere is a CERTAIN miss
-    // for every pixel, not an unsure one); the loop below then visits the set bits only.
+    // i from its CullRec (radius enlarged by the error band of the float32 hit test, so a culled sphere is a
+    // CERTAIN miss for every pixel, not an unsure one; the square roots come from the host); the loop below
+    // then visits the set bits only.
     unsigned cand = (1u << n) - 1u;                    // n <= PTR_FAST_MAX_SPHERES
     if (a.cull_on) {
         const int x0 = blockIdx.x * (PTR_FAST_BLOCK / 64 * 8 * PPL) + wave * (8 * PPL), row0 = blockIdx.y * PTR_TILE_H;
@@ -134,13 +138,9 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
             dc = F3{xc, yc, -1.0f};
         }
         const float inv = rsq(dot3(dc, dc));
-        const float4 g0 = cull_g0, g1 = cull_g1;
-        const float bc = dot3(F3{g0.x, g0.y, g0.z}, dc) * inv;
-        const float cce = fmaf(-2.0f, g1.x, g0.w);                           // |l|^2 - (r^2 + 2 md)
-        const float sce = __builtin_amdgcn_sqrtf(fmaxf(cce, 0.0f));
-        const float re = __builtin_amdgcn_sqrtf(fmaf(2.0f, g1.x, g1.z));
-        const float K = fmaf(a.cull_cos, sce, -fmaf(a.cull_sin, re, 1e-5f * g1.w));   // 1e-5 |l|: rounding of all of this
-        cand = (unsigned)(ballot(cce <= 0.0f) | ballot(bc >= K)) & ((1u << n) - 1u);
+        const float bc = dot3(F3{cull_g0.x, cull_g0.y, cull_g0.z}, dc) * inv;
+        const float K = fmaf(a.cull_cos, cull_g0.w, -fmaf(a.cull_sin, cull_g1.x, cull_g1.y));
+        cand = (unsigned)ballot(bc >= K) & ((1u << n) - 1u);
     }
 
     stamp(2);
