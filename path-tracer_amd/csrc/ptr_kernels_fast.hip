@@ -285,11 +285,12 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
 
             // ---- hit frame (RayTracer.js:48-58), camera-relative -------------------------------
             s.P = F3{d.x * s.t, d.y * s.t, d.z * s.t};
-            F3 N{s.P.x - lw.x, s.P.y - lw.y, s.P.z - lw.z};    // P - C (Sphere.js:47-51)
-            const float inv = rsq(dot3(N, N));
-            const float sg = outside ? inv : -inv;     // inside: d.N > 0 -> revert (RayTracer.js:54-58)
+            // P - C (Sphere.js:47-51), normalised by 1 / r: the true hit point lies ON the sphere, so this differs from
+            // the true normal by (error of P) / r, which eN below already counts
+            F3 N{s.P.x - lw.x, s.P.y - lw.y, s.P.z - lw.z};
+            const float sg = outside ? inv_r : -inv_r; // inside: d.N > 0 -> revert (RayTracer.js:54-58)
             s.N = F3{N.x * sg, N.y * sg, N.z * sg};
-            s.eN = fmaf(s.eP + EPS * (lnorm_w + s.t), inv_r, 3.0f * EPS);   // |error of N|
+            s.eN = fmaf(s.eP + EPS * (lnorm_w + s.t), inv_r, 5.0f * EPS);   // |error of N| (1 / r itself: 2 eps)
             s.ar = 0.0f; s.ag = 0.0f; s.ab = 0.0f; s.wsum = 0.0f; s.eLmax = 0.0f;
         }
         // (after the arithmetic above: this is the first use of a word requested at the top)
