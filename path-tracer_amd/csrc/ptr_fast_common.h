@@ -74,11 +74,25 @@ __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x);
 __device__ __forceinline__ unsigned long long ballot(bool c) { return __builtin_amdgcn_ballot_w64(c); }
 __device__ __forceinline__ bool lane_of(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
-// a per-lane 16-byte load that stays where it is written (the compiler otherwise sinks it next to its first use)
-__device__ __forceinline__ float4 load_f4(const volatile float4* p)
+// A per-lane 16-byte load that is issued where it is written (the compiler otherwise sinks a plain load next to its first
+// use, inside a branch) and waited for only at its first use.  Not a volatile load: on gfx950 that is a cache-bypassing
+// flat load followed by an immediate wait.  A relaxed atomic load at wavefront scope is an ordinary global_load that the
+// optimiser neither sinks nor duplicates.
+__device__ __forceinline__ float4 load_f4(const float4* p)
 {
-    const f4 v = *reinterpret_cast<const volatile f4*>(p);
-    return make_float4(v.x, v.y, v.z, v.w);
+    const uint64_t* q = reinterpret_cast<const uint64_t*>(p);
+    const uint64_t lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    const uint64_t hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    return make_float4(__uint_as_float((uint32_t)lo), __uint_as_float((uint32_t)(lo >> 32)),
+                       __uint_as_float((uint32_t)hi), __uint_as_float((uint32_t)(hi >> 32)));
+}
+
+// ... and 12 bytes (no fourth word: a destination register nobody reads is reused at once, and the reuse waits for the load)
+__device__ __forceinline__ F3 load_f3(const float* p)
+{
+    const uint64_t lo = __hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    const uint32_t z = __hip_atomic_load(reinterpret_cast<const uint32_t*>(p) + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    return F3{__uint_as_float((uint32_t)lo), __uint_as_float((uint32_t)(lo >> 32)), __uint_as_float(z)};
 }
 
 // lane `l`'s value of v as a wave-uniform value

@@ -253,9 +253,9 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
         const volatile uint32_t PTR_CONST* hw = (const volatile uint32_t PTR_CONST*)(uintptr_t)block;
         const int nl = (int)hw[offsetof(FrameHeader, n_lights) / 4];
         const bool self_ok = hw[offsetof(FrameHeader, self_skip) / 4] != 0u;
-        const volatile float4* lane_pairs = reinterpret_cast<const volatile float4*>(block + a.off_pairs) + li;
+        const float4* lane_pairs = reinterpret_cast<const float4*>(block + a.off_pairs) + li;
         float4 pq = load_f4(lane_pairs);
-        const float4 cj = load_f4(reinterpret_cast<const volatile float4*>(&gp32[li].lx));
+        const F3 cj = load_f3(&gp32[li].lx);
 #pragma unroll
         for (int p = 0; p < PPL; p++) {
             Pixel& r = px[p];
@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
         // |a_j . L| >= thr_j (PairQ), and |a_j . L| <= |a_j . axis| + dmax: lane j tests element j against the cone, and
         // the ballot is a wave-uniform bit per occluder, "some open lane may reach it".  One compare -> mask round
         // trip per light instead of one per occluder.
-        auto cone_prefilter = [&](const float4 pq, const float4 cj) -> unsigned {
+        auto cone_prefilter = [&](const float4 pq, const F3 cj) -> unsigned {
             const unsigned long long o0 = sh[0].open_m;
             const bool first = o0 != 0ull || PPL == 1;                       // wave-uniform
             const Shade& sa = sh[first ? 0 : PPL - 1];
