@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
             const float m = fminf(b * q.g1.y, disc);   // hit <=> b >= 0 && disc >= 0 <=> m >= 0
             const unsigned long long hit_m = ballot(m >= 0.0f);
             unsure[p].add_mask(ballot(fabsf(m) <= q.g1.x) & poss_m, WHY_PRIMARY);
-            unsure[p].add_mask(cc_flag ? hit_m : 0ull, WHY_CC);
+            if (cc_flag) unsure[p].add_mask(hit_m, WHY_CC);    // wave-uniform, rare: a branch instead of four selects
             // Branch-free for the lanes that miss (they carry t = "never" and add no error): switching lanes off and on
             // costs more than the two selects.  Only the copy of a new leader's record is predicated.
             const bool hit = m >= 0.0f;
@@ -415,11 +415,12 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
         };
 
         static_assert(PTR_FAST_MAX_SPHERES <= 16 && PTR_FAST_MAX_SPHERES <= PTR_MAX_PAIR_LIGHTS, "light k has pre-filter row k");
+        ConstF4 lrp = lrec0, pairs = pairs0;                 // light k's record / pre-filter row: stepped, not indexed
+        const unsigned pstride = (unsigned)pair_stride(n);
+        const float4* lane_row = lane_pairs;
         for (int k = 0; k < nl; k++) {
             arrive(lq);
             const unsigned i = (unsigned)lq.index & 15u;       // (the mask tells the compiler that the index is small)
-            const unsigned prow = (unsigned)k * (unsigned)pair_stride(n);
-            const ConstF4 pairs = pairs0 + prow;
             const F3 lpos{lq.g.x, lq.g.y, lq.g.z};
             const float llnorm = lq.g.w;
             const float ler = lq.e.x, leg = lq.e.y, leb = lq.e.z, lemax = lq.e.w;
@@ -455,8 +456,9 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
                 s.eLmax = fmax_raw(s.eLmax, lit ? s.eL : 0.0f);
             }
             // the next light's record and pre-filter row (the tables end with a padding record / row)
-            lq = load_light(lrec0 + 3 * (k + 1));
-            pq = load_f4(lane_pairs + (prow + (unsigned)pair_stride(n)));
+            lrp += 3; pairs += pstride; lane_row += pstride;
+            lq = load_light(lrp);
+            pq = load_f4(lane_row);
         }
 
         stamp(5);
