@@ -319,6 +319,10 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
 
         // ---- direct light + binary shadow (RayTracer.js:61-91) ---------------------------------
         // one shadow test of sphere record pj for every pixel slot
+        // What the float64 re-do of a pixel that only has its ROUNDING in doubt may take over (retrace kind 1,
+        // ptr_kernels_exact.hip reshade_exact): light k "certainly blocked" = bit 8 + 2k of the lane's idx register
+        // (n <= 12: the index itself fits the low byte); k is the light being worked on.
+        int k = 0;
         auto shadow = [&](const P32H& pj, int j) {
             if constexpr (DBG) dbg_pre_tests++;
             // Pre-filter: the shadow ray leaves (within the 1e-4 bias) along the line through the
@@ -360,6 +364,7 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
                 const unsigned long long certain = ballot(bj > ebj) & ballot(disc > band);
                 const unsigned long long possible = ballot(bj >= -ebj) & ballot(disc >= -band);
                 s.maybe_m |= possible & ~certain;
+                if constexpr (HYBRID) px[p].idx |= lane_of(certain & s.open_m) ? (int)(0x100u << (2 * k)) : 0;
                 if constexpr (!HYBRID)                 // the float32 verdict only shows in f32-only output
                     s.blocked_m |= ballot(bj >= 0.0f) & ballot(disc >= 0.0f);
                 s.open_m &= ~certain;
@@ -418,7 +423,7 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
         ConstF4 lrp = lrec0, pairs = pairs0;                 // light k's record / pre-filter row: stepped, not indexed
         const unsigned pstride = (unsigned)pair_stride(n);
         const float4* lane_row = lane_pairs;
-        for (int k = 0; k < nl; k++) {
+        for (k = 0; k < nl; k++) {
             arrive(lq);
             const unsigned i = (unsigned)lq.index & 15u;       // (the mask tells the compiler that the index is small)
             const F3 lpos{lq.g.x, lq.g.y, lq.g.z};
@@ -444,8 +449,10 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
 #pragma unroll
             for (int p = 0; p < PPL; p++) {
                 Shade& s = sh[p];
-                // A "maybe" only matters if no certain hit blocks the light anyway.
+                // A "maybe" only matters if no certain hit blocks the light anyway.  N.L within its error of 0 is a
+                // "maybe" too: the float64 value may be positive where this one is not, and then the light counts.
                 unsure[p].add_mask(s.open_m & s.maybe_m, WHY_SHADOW);
+                if constexpr (HYBRID) unsure[p].add_mask(ballot(fabsf(s.ratio) <= s.eN + s.eL) & s.valid_m, WHY_SHADOW);
                 // branch-free: an unlit lane adds zeros (selects cost less than switching lanes off and on again)
                 const bool lit = lane_of(s.open_m & ~s.blocked_m);
                 const float wr = lit ? s.ratio : 0.0f;
@@ -468,7 +475,7 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
         // (RayTracer.js:85-93)
         SphereM32 mws[PPL];
 #pragma unroll
-        for (int p = 0; p < PPL; p++) mws[p] = gm32[sh[p].valid ? px[p].idx : 0];
+        for (int p = 0; p < PPL; p++) mws[p] = gm32[sh[p].valid ? (px[p].idx & 0xFF) : 0];
 #pragma unroll
         for (int p = 0; p < PPL; p++) {
             Shade& s = sh[p];
@@ -483,6 +490,9 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
             const float qr = __builtin_amdgcn_fractf(vr) - 0.5f, qg = __builtin_amdgcn_fractf(vg) - 0.5f,
                         qb = __builtin_amdgcn_fractf(vb) - 0.5f;
             const float nearest = fminf(fminf(fabsf(qr), fabsf(qg)), fabsf(qb));
+            // HYBRID: a pixel in doubt for any OTHER reason is re-traced from scratch (bit 9 of its idx register: one lane
+            // mask, not two, stays in SGPRs); one that is only here for its rounding gets the shading-only re-do
+            if constexpr (HYBRID) px[p].idx |= unsure[p].any() ? 0x200 : 0;
             unsure[p].add_mask(ballot(nearest <= band) & s.valid_m, WHY_ROUND);
             const uint32_t r8 = (uint32_t)(vr + 0.5f), g8 = (uint32_t)(vg + 0.5f), b8 = (uint32_t)(vb + 0.5f);
             // (a select, spelled out: the compiler otherwise switches the unshaded lanes off around the conversion above)
@@ -521,15 +531,30 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
         }
         if constexpr (HYBRID) {
             if (unsure[p].mask == 0ull) continue;      // wave-uniform: nearly every wave leaves here
-            if (unsure[p].any() & (st8 | (in_img & (a.out32f != nullptr)))) {
+            const bool may = st8 | (in_img & (a.out32f != nullptr));
+            const bool full = (r.idx & 0x200) != 0 || r.idx < 0;      // (a miss has nothing to re-shade)
+            if (unsure[p].any() & may) {
                 // one counter word would saturate (~88 returning atomics/us chip-wide): the queue is
                 // cut into n_queues sub-queues, each with its own counter line, chosen by workgroup
                 uint32_t bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
                 asm volatile("" : "+s"(bid));           // keeps the address arithmetic below behind the branch above
                 const uint32_t sub = bid & (a.n_queues - 1u);       // n_queues is a power of two
-                const uint32_t q = atomicAdd(a.counter + sub * PTR_COUNTER_STRIDE, 1u);
-                if (q < a.queue_capacity)
-                    a.queue[(uint64_t)sub * a.queue_capacity + q] = (uint32_t)(frame * frame_px + (uint64_t)pix);
+                const uint32_t gid = (uint32_t)(frame * frame_px + (uint64_t)pix);
+                if (full) {
+                    // kind 0, from the front of the sub-queue: re-trace from scratch
+                    const uint32_t q = atomicAdd(a.counter + sub * PTR_COUNTER_STRIDE, 1u);
+                    if (q < a.queue_capacity) a.queue[(uint64_t)sub * a.queue_capacity + q] = gid;
+                } else {
+                    // kind 1, from its back (a pixel is queued once, so the two never meet): nearest element and shadow
+                    // verdicts are certain, only the shading is redone in float64
+                    const uint32_t q = atomicAdd(a.counter + sub * PTR_COUNTER_STRIDE + 1, 1u);
+                    if (q < a.queue_capacity) {
+                        const uint64_t slot = (uint64_t)sub * a.queue_capacity + (a.queue_capacity - 1u - q);
+                        a.queue[slot] = gid;
+                        a.qinfo[2 * slot] = (uint32_t)r.idx & 0xFFu;
+                        a.qinfo[2 * slot + 1] = ((uint32_t)r.idx >> 8) & 0x555555u;
+                    }
+                }
             }
         }
     }
