@@ -69,7 +69,11 @@ def test_big_frame_hashes(rdr, golden_index, scenes, key, mode):
     assert not got[(h - 1) * w:].any()          # F5: last stored row untouched
     if mode == "hybrid":
         st = rdr.stats()
-        assert 0 < st["retraced"] < 0.15 * w * h, st
+        assert 0 < st["retraced"] + st["reshaded"] < 0.15 * w * h, st
+        # doubts about the 8-bit rounding alone take the shading-only float64 re-do (most of them on the example scene)
+        assert st["reshaded"] > 0 and st["retraced"] > 0, st
+        if key.startswith("example1"):
+            assert st["reshaded"] > st["retraced"], st
 
 
 @pytest.mark.parametrize("mode", ["exact", "hybrid"])
