@@ -122,6 +122,32 @@ def test_few_sphere_kernel_random_scenes_ragged_sizes(rdr):
         assert bad.size == 0, f"trial {trial} (n={n}, {w}x{h}): {bad.size} pixels differ, first {bad[:5]}"
 
 
+def test_few_sphere_kernel_every_element_a_light(rdr):
+    """12 elements, all emissive: 12 lights is the most the few-sphere kernel sees, and the shading-only float64 re-do is handed
+    one "certainly blocked" bit per light (bits 8, 10, ... 30 of a lane's index register).  Spheres in a tight cluster, so
+    that most shadow rays do meet an occluder."""
+    rng = np.random.default_rng(7020)
+    rdr.set_camera(None)
+    for trial in range(3):
+        n = 12
+        soa = np.zeros((12, n))
+        soa[0] = rng.uniform(-5, 5, n); soa[1] = rng.uniform(-3, 4, n); soa[2] = rng.uniform(-26, -14, n)
+        soa[3] = rng.uniform(0.8, 2.5, n)
+        soa[4:7] = rng.uniform(0.1, 1.0, (3, n))
+        soa[9:12] = rng.uniform(0.02, 0.25, (3, n))
+        if trial == 2:
+            soa[0:4, 0] = [0, -1004, -20, 1000]
+        bg = rng.uniform(0, 1.0, 3)
+        w, h = 333, 171
+        rdr.set_scene(soa); rdr.set_background(bg)
+        got = rdr.render(w, h, flags=0)
+        st = rdr.stats()
+        want = orc.render(soa, bg, w, h, flags=0, threads=8)
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, f"trial {trial}: {bad.size} pixels differ, first {bad[:5]}"
+        assert st["reshaded"] > 0, st
+
+
 def test_few_sphere_kernel_moved_camera_and_inside_a_sphere(rdr):
     """general camera (the culling cone follows it) from several places, one of them inside a big sphere"""
     rng = np.random.default_rng(7013)
