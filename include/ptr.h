@@ -86,7 +86,7 @@ typedef struct ptr_ctx ptr_ctx;
 #define PTR_MAX_DEPTH_LIMIT 16
 #define PTR_MAX_SPP         65536
 typedef struct ptr_params {
-    int32_t  width;        /* full image width  (RayTracer.js:150,153)                        */
+    int32_t  width;        /* full image width  (RayTracer.js:150,153); 1 .. 2^24 - 1          */
     int32_t  height;       /* full image height (RayTracer.js:151,153)                        */
     int32_t  start_y;      /* first scanline of the band (RayTracer.js:134-136), default 0    */
     int32_t  scan_height;  /* rows in the band (RayTracer.js:138-140), default = height       */
