@@ -290,6 +290,9 @@ def test_errors(scenes):
         import ctypes as C
         rc = ptr_amd.lib().ptr_render(r._h, C.byref(p), out.ctypes.data_as(C.POINTER(C.c_uint32)), None)
         assert rc == ptr_amd.ERR_INVALID
+        p = r.params(1 << 24, 8, 0, 1)            # the kernels index pixels with 24-bit multiplies: refused before any launch
+        rc = ptr_amd.lib().ptr_render(r._h, C.byref(p), out.ctypes.data_as(C.POINTER(C.c_uint32)), None)
+        assert rc == ptr_amd.ERR_INVALID and b"width" in ptr_amd.lib().ptr_last_error(r._h)
         with pytest.raises(ptr_amd.PtrError):
             ptr_amd.Renderer(99)
     finally:
