@@ -79,13 +79,8 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
     [[maybe_unused]] unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // DBG: clock at the stage boundaries
     auto stamp = [&](int k) { if constexpr (DBG) ts[k] = __builtin_readcyclecounter(); };
     stamp(0);
-#pragma unroll
-    for (int p = 0; p < PPL; p++) {
-        Pixel& q = px[p];
-        q.x = blockIdx.x * (PTR_FAST_BLOCK / 64 * 8 * PPL) + wave * (8 * PPL) + p * 8 + (lane & 7);
-        q.row = blockIdx.y * PTR_TILE_H + (lane >> 3);
-        q.live = (q.x < a.width) & (q.row < a.scan_height);
-        // camera ray (RayTracer.js:171-174)
+    // camera ray of a pixel slot (RayTracer.js:171-174)
+    auto camera_ray = [&](Pixel& q) {
         const float xx = fmaf((float)q.x + 0.5f, a.camf.sx, a.camf.ox);
         const float yy = fmaf((float)global_y(a, q.row) + 0.5f, a.camf.sy, a.camf.oy);
         F3 d;
@@ -98,6 +93,13 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
         }
         const float inv = rsq(dot3(d, d));
         q.d = F3{d.x * inv, d.y * inv, d.z * inv};
+    };
+#pragma unroll
+    for (int p = 0; p < PPL; p++) {
+        Pixel& q = px[p];
+        q.x = blockIdx.x * (PTR_FAST_BLOCK / 64 * 8 * PPL) + wave * (8 * PPL) + p * 8 + (lane & 7);
+        q.row = blockIdx.y * PTR_TILE_H + (lane >> 3);
+        q.live = (q.x < a.width) & (q.row < a.scan_height);
         q.tnear = 3.0e38f; q.t2 = 3.0e38f; q.etmax = 0.0f; q.idx = -1;
     }
     {
@@ -199,6 +201,10 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
             const unsigned stop = 1u << n;             // record n: the zero padding
             int i = __builtin_ctz(todo);
             P32Q A = load_p32(rec0 + 4u * (unsigned)i), B;
+            // the camera rays are only worked out here: a wave whose tile no sphere can reach (sky) never needs them, and
+            // the first candidate's record is on its way meanwhile
+#pragma unroll
+            for (int p = 0; p < PPL; p++) camera_ray(px[p]);
             // (two steps per trip, the buffers swapping roles: no record is copied from one set of SGPRs to the other)
             auto step = [&](const P32Q& cur, P32Q& next) {
                 todo &= todo - 1u;
