@@ -229,23 +229,27 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
     unsigned long long shaded_m[PPL];
     uint32_t packed[PPL];
     Shade sh[PPL];
-    bool any_valid = false;
+    bool shade_wave = false;                   // wave-uniform: some lane hit something
+    if (cand != 0u) {                          // (a wave without candidates goes straight to the background)
+        bool any_valid = false;
 #pragma unroll
-    for (int p = 0; p < PPL; p++) {
-        Pixel& r = px[p];
-        // (lanes outside the image trace a ray like every other and are only kept from storing: `live` is not needed here)
-        sh[p].valid = r.idx >= 0;
-        sh[p].valid_m = ballot(sh[p].valid);
-        // nearest-vs-second ordering, far clip (t < 1e8, RayTracer.js:19,36).  (A compare writes its lane mask directly;
-        // the ballot of `compare & bool` costs two more vector instructions.)
-        unsure[p].add_mask(ballot(r.t2 - r.tnear <= 2.0f * r.etmax) & sh[p].valid_m, WHY_ORDER);
-        unsure[p].add_mask(ballot(r.tnear >= FAR_UNSURE) & sh[p].valid_m, WHY_FAR);
-        any_valid |= sh[p].valid;
+        for (int p = 0; p < PPL; p++) {
+            Pixel& r = px[p];
+            // (lanes outside the image trace a ray like every other and are only kept from storing: `live` is not needed here)
+            sh[p].valid = r.idx >= 0;
+            sh[p].valid_m = ballot(sh[p].valid);
+            // nearest-vs-second ordering, far clip (t < 1e8, RayTracer.js:19,36).  (A compare writes its lane mask directly;
+            // the ballot of `compare & bool` costs two more vector instructions.)
+            unsure[p].add_mask(ballot(r.t2 - r.tnear <= 2.0f * r.etmax) & sh[p].valid_m, WHY_ORDER);
+            unsure[p].add_mask(ballot(r.tnear >= FAR_UNSURE) & sh[p].valid_m, WHY_FAR);
+            any_valid |= sh[p].valid;
+        }
+        shade_wave = ballot(any_valid) != 0ull;
     }
 
     // Wave-uniform branch: taken when any lane hit something; lanes that missed run along on
     // sphere 0 with every flag and result masked by `valid` (keeps all control flow below scalar).
-    if (ballot(any_valid) != 0ull) {
+    if (shade_wave) {
         // A shadow ray never hits the sphere it starts on when that sphere was hit from outside: its origin is
         // P + 1e-4 N, at distance r + 1e-4 from the centre, so tca = l.L = -(r + 1e-4) N.L <= 0 whenever the light is
         // in front (N.L > 0), and should rounding lift tca to 0, d2 = |l|^2 - tca^2 > r^2 by 2e-4 r (Sphere.js:19-25).
