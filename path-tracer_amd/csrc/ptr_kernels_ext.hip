@@ -413,7 +413,7 @@ template <typename T, bool STATS>
 __global__ void __launch_bounds__(PTR_BLOCK) render_ext_kernel(RenderArgs a)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = blockIdx.x * PTR_TILE_W + wave * 8 + (lane & 7);
+    const int x = blockIdx.x * (int)(blockDim.x >> 3) + wave * 8 + (lane & 7);      // 8 x 8 pixels per wave, the waves side by side
     const int row = blockIdx.y * PTR_TILE_H + (lane >> 3);
     ExtCounts cnt;
     if (x < a.width && row < a.scan_height) render_ext_pixel<T, STATS>(a, x, row, &cnt);
@@ -436,7 +436,12 @@ hipError_t launch_render_ext(const RenderArgs& a, int n_frames, bool f64, bool s
     dim3 grid((a.width + PTR_TILE_W - 1) / PTR_TILE_W, (a.scan_height + PTR_TILE_H - 1) / PTR_TILE_H, n_frames);
     if (stats) hipLaunchKernelGGL((render_ext_kernel<double, true>), grid, dim3(PTR_BLOCK), 0, s, a);
     else if (f64) hipLaunchKernelGGL((render_ext_kernel<double, false>), grid, dim3(PTR_BLOCK), 0, s, a);
-    else     hipLaunchKernelGGL((render_ext_kernel<float, false>), grid, dim3(PTR_BLOCK), 0, s, a);
+    else {
+        // one wave per workgroup: the waves' run times differ by an order of magnitude (a tile on a transparent sphere
+        // expands a tree of rays), and a one-wave workgroup starts wherever a slot is free
+        const dim3 grid1((a.width + 7) / 8, grid.y, n_frames);
+        hipLaunchKernelGGL((render_ext_kernel<float, false>), grid1, dim3(64), 0, s, a);
+    }
     return hipGetLastError();
 }
 
