@@ -42,7 +42,8 @@ struct Shade {
     int   self;                 // the element the pixel lies on, seen from outside (-1: none / seen from inside)
     F3    P, N;                 // hit point, normal (camera-relative)
     float t, eP, eN;
-    float ar, ag, ab, wsum, eLmax;   // sum over the unblocked lights of emission * N.L per channel, ...
+    float ar, ag, ab, werr;          // sum over the unblocked lights of emission * N.L per channel; of (largest emission
+                                     //   channel) * (error bound of that light's N.L)
     // per light
     F3    L;
     float ratio, eL;            // N.L, |error of L| (+ 3 eps: see the pre-filter)
@@ -300,8 +301,9 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
             F3 N{s.P.x - lw.x, s.P.y - lw.y, s.P.z - lw.z};
             const float sg = outside ? inv_r : -inv_r; // inside: d.N > 0 -> revert (RayTracer.js:54-58)
             s.N = F3{N.x * sg, N.y * sg, N.z * sg};
-            s.eN = fmaf(s.eP + EPS * (lnorm_w + s.t), inv_r, 5.0f * EPS);   // |error of N| (1 / r itself: 2 eps)
-            s.ar = 0.0f; s.ag = 0.0f; s.ab = 0.0f; s.wsum = 0.0f; s.eLmax = 0.0f;
+            s.eN = fmaf(s.eP + EPS * (lnorm_w + s.t), inv_r, 15.0f * EPS);  // |error of N| (1 / r itself: 2 eps), + 10 eps for the
+                                                                            //   rounding of N.L and of the sums over the lights
+            s.ar = 0.0f; s.ag = 0.0f; s.ab = 0.0f; s.werr = 0.0f;
         }
         // (after the arithmetic above: this is the first use of a word requested at the top)
 #pragma unroll
@@ -462,15 +464,15 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
                 // A "maybe" only matters if no certain hit blocks the light anyway.  N.L within its error of 0 is a
                 // "maybe" too: the float64 value may be positive where this one is not, and then the light counts.
                 unsure[p].add_mask(s.open_m & s.maybe_m, WHY_SHADOW);
-                if constexpr (HYBRID) unsure[p].add_mask(ballot(fabsf(s.ratio) <= s.eN + s.eL) & s.valid_m, WHY_SHADOW);
+                const float enl = s.eN + s.eL;                 // |error of N.L| (the rounding of the dot and of the sums is in eN)
+                if constexpr (HYBRID) unsure[p].add_mask(ballot(fabsf(s.ratio) <= enl) & s.valid_m, WHY_SHADOW);
                 // branch-free: an unlit lane adds zeros (selects cost less than switching lanes off and on again)
                 const bool lit = lane_of(s.open_m & ~s.blocked_m);
                 const float wr = lit ? s.ratio : 0.0f;
                 s.ar = fmaf(ler, wr, s.ar);
                 s.ag = fmaf(leg, wr, s.ag);
                 s.ab = fmaf(leb, wr, s.ab);
-                s.wsum += lit ? lemax : 0.0f;
-                s.eLmax = fmax_raw(s.eLmax, lit ? s.eL : 0.0f);
+                s.werr = fmaf(lit ? lemax : 0.0f, enl, s.werr);
             }
             // the next light's record and pre-filter row (the tables end with a padding record / row)
             lrp += 3; pairs += pstride; lane_row += pstride;
@@ -493,7 +495,7 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
             const float hr = fmaf(mw.sr, s.ar, mw.er), hg = fmaf(mw.sg, s.ag, mw.eg), hb = fmaf(mw.sb, s.ab, mw.eb);
             // ---- clamp, round, pack (RayTracer.js:179-192) with a rounding bound ----------------
             // |error of N.L| <= eN + eL (+ rounding of the dot and of the sums, 8 eps)
-            const float band = 255.0f * fmaf(mw.scmax * s.wsum, s.eN + s.eLmax + 10.0f * EPS, 4.0f * EPS * mw.emax) + 2e-5f;
+            const float band = 255.0f * fmaf(mw.scmax, s.werr, 4.0f * EPS * mw.emax) + 2e-5f;
             // Math.round(v) = floor(v + 0.5); v + 0.5 is exact in float32 for 0.5 <= v < 256, and below 0.5 it can only
             // round across 1.0 within the band that is re-traced anyway
             const float vr = fmin_raw(hr, 1.0f) * 255.0f, vg = fmin_raw(hg, 1.0f) * 255.0f, vb = fmin_raw(hb, 1.0f) * 255.0f;
