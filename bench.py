@@ -35,10 +35,10 @@ STRIP = 8
 PEAK_FP32_VALU_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
 PEAK_HBM_GBPS = 8000.0
 # HBM traffic of the float32 kernel per pixel, from the PMC passes of this very command kept under profiles/
-# (r01_summary.md: WRITE_SIZE 559 754 KB and FETCH_SIZE 902.1 KB per launch of 64 x 1920 x 1080 pixels; gfx950
+# (r01_summary.md: WRITE_SIZE 559 662 KB and FETCH_SIZE 908.1 KB per launch of 64 x 1920 x 1080 pixels; gfx950
 # correction of the guide applied: FETCH_SIZE counts 64 B per 128-B request -> x 2).  Counters cannot be read from
 # inside this process, so the per-launch figure reported below is this measured rate times the launch's pixels.
-MEASURED_HBM_BYTES_PER_PIXEL = (559754.0 * 1024 + 2 * 902.13 * 1024) / (64 * 1920 * 1080)
+MEASURED_HBM_BYTES_PER_PIXEL = (559662.0 * 1024 + 2 * 908.146 * 1024) / (64 * 1920 * 1080)
 
 
 def example1_soa():
