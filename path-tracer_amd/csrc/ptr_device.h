@@ -11,7 +11,7 @@
 #define PTR_INFINITY 1e8      // RT/src/RayTracer.js:6 — finite far clip
 #define PTR_BIAS     1e-4     // RT/src/RayTracer.js:52
 
-#define PTR_TILE_W 32         // workgroup tile: 4 waves side by side, each an 8x8 pixel tile
+#define PTR_TILE_W 32         // workgroup tile of the 256-thread kernels: 4 waves side by side, each an 8x8 pixel tile
 #define PTR_TILE_H 8
 #define PTR_BLOCK  256
 #define PTR_FAST_BLOCK 64     // few-sphere kernel: one wave per workgroup (no LDS, no barrier: a wave then starts wherever a slot is free)

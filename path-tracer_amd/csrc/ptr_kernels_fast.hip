@@ -6,7 +6,11 @@
 //     loads (constant address space -> s_load_dwordx8/x4) and sit in SGPRs: no vector memory,
 //     no LDS, no bank conflicts.  Each record is requested one sphere ahead of its use;
 //   * the geometry is camera-relative and the per-sphere terms |l|^2 - r^2 etc. are computed
-//     once in float64 on the host, so the primary test is 3 FMAs + 1 FMA;
+//     once in float64 on the host, so the primary test is 3 FMAs + 1 compare;
+//   * a wave's pixels are one 16 x 8 tile of the image: lane i first tests sphere i against the cone of
+//     the tile's rays, and the primary loop visits only the spheres some ray of the tile can reach; the
+//     shadow loop is culled per wave the same way (cone of the wave's shadow rays against the
+//     light -> occluder cones of the host's table);
 //   * everything past the hit/miss test of a sphere is skipped by the whole wave when no lane
 //     hits it (exec-mask branch); the shadow loop leaves as soon as every lane is decided;
 //   * all bookkeeping booleans (who is still undecided, who is "not sure") live as 64-bit lane
@@ -16,7 +20,8 @@
 // Every discontinuous decision (hit/miss, which sphere is nearest, shadowed or not, the
 // 8-bit rounding) carries a conservative error bound.  In HYBRID mode a pixel with any
 // decision inside its bound is appended to a queue and re-traced afterwards by the float64
-// kernel (ptr_kernels_exact.hip); all other pixels already hold the reference's bytes.
+// kernel (ptr_kernels_exact.hip) - re-shaded only, when its 8-bit rounding is the one thing in
+// doubt; all other pixels already hold the reference's bytes.
 #include <hip/hip_runtime.h>
 #include "ptr_device.h"
 #include "ptr_kernels.h"
@@ -73,7 +78,7 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
     const float4 cull_g0 = *reinterpret_cast<const float4*>(&gcull[li].lx);   // lx ly lz s
     const float2 cull_g1 = *reinterpret_cast<const float2*>(&gcull[li].re);   // re c
 
-    // ---- this lane's pixels: an (8*PPL) x 8 tile per wave (the pixel slots side by side: a tile never straddles two 8-row strips), (32*PPL) x 8 per workgroup ------------
+    // ---- this lane's pixels: an (8*PPL) x 8 tile per wave (the pixel slots side by side: a tile never straddles two 8-row strips), one wave per workgroup ------------
     Pixel px[PPL];
     [[maybe_unused]] unsigned dbg_full_tests = 0, dbg_pre_tests = 0;   // DBG: shadow tests this wave ran
     Unsure<DBG> unsure[PPL];
