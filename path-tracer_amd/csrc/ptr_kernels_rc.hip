@@ -247,8 +247,10 @@ hipError_t launch_rc_shade(const RcShadeArgs& a, hipStream_t s)
 size_t rc_sort_temp_bytes(int n_items, int width, int height)
 {
     size_t bytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                       (const uint32_t*)nullptr, (uint32_t*)nullptr, n_items, 0, rc_key_bits(width, height));
+    // (a size query: no work is launched; on an error the caller's allocation of 0 bytes makes the sort itself fail loudly)
+    if (hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+                                           (uint32_t*)nullptr, n_items, 0, rc_key_bits(width, height)) != hipSuccess)
+        return 0;
     return bytes;
 }
 
