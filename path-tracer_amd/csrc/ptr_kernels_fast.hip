@@ -85,10 +85,22 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
     [[maybe_unused]] unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // DBG: clock at the stage boundaries
     auto stamp = [&](int k) { if constexpr (DBG) ts[k] = __builtin_readcyclecounter(); };
     stamp(0);
+    // Image row of this lane's pixels (the same for every slot).  With cyclic strips that is a division per lane - unless the
+    // tile's 8 rows are consecutive image rows (bands, strips of a multiple of 8 rows): then it is the tile's first row, a
+    // wave-uniform value worked out on the scalar side, plus the lane's row in the tile.
+    const int tile_row0 = blockIdx.y * PTR_TILE_H;
+    int gy0 = 0, gy;
+    if (a.n_parts <= 1 || a.strip_h % PTR_TILE_H == 0) {
+        gy0 = global_y(a, tile_row0);
+        gy = gy0 + (lane >> 3);
+    } else {
+        asm volatile("");                          // (keeps this a branch: the compiler would compute both forms and select)
+        gy = global_y(a, tile_row0 + (lane >> 3));
+    }
     // camera ray of a pixel slot (RayTracer.js:171-174)
     auto camera_ray = [&](Pixel& q) {
         const float xx = fmaf((float)q.x + 0.5f, a.camf.sx, a.camf.ox);
-        const float yy = fmaf((float)global_y(a, q.row) + 0.5f, a.camf.sy, a.camf.oy);
+        const float yy = fmaf((float)gy + 0.5f, a.camf.sy, a.camf.oy);
         F3 d;
         if constexpr (GENERAL) {          // a kernel of its own: as a run-time test the compiler computes both forms and selects
             d.x = fmaf(xx, a.camf.right[0], fmaf(yy, a.camf.up[0], a.camf.fwd[0]));
@@ -136,7 +148,7 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
     if (a.cull_on) {
         const int x0 = blockIdx.x * (PTR_FAST_BLOCK / 64 * 8 * PPL) + wave * (8 * PPL), row0 = blockIdx.y * PTR_TILE_H;
         const float xc = fmaf((float)(x0 + 4 * PPL), a.camf.sx, a.camf.ox);
-        const float yc = fmaf((float)(global_y(a, row0) + PTR_TILE_H / 2), a.camf.sy, a.camf.oy);
+        const float yc = fmaf((float)(gy0 + PTR_TILE_H / 2), a.camf.sy, a.camf.oy);     // (cull_on implies consecutive rows)
         F3 dc;
         if constexpr (GENERAL) {
             dc.x = fmaf(xc, a.camf.right[0], fmaf(yc, a.camf.up[0], a.camf.fwd[0]));
