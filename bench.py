@@ -30,15 +30,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd", "py"))
 
 WIDTH, HEIGHT = 1920, 1080
-FRAMES_PER_GPU = 64
+FRAMES_PER_GPU = 256         # per launch: 2.1 GB of RGBA8 per GPU; 64 -> 256 frames per launch is +11 % (launch ramp and gaps amortised)
 STRIP = 8
 PEAK_FP32_VALU_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
 PEAK_HBM_GBPS = 8000.0
 # HBM traffic of the float32 kernel per pixel, from the PMC passes of this very command kept under profiles/
-# (r01_summary.md: WRITE_SIZE 559 662 KB and FETCH_SIZE 908.1 KB per launch of 64 x 1920 x 1080 pixels; gfx950
+# (r01_summary.md: WRITE_SIZE 2 238 650 KB and FETCH_SIZE 3 499.8 KB per launch of 256 x 1920 x 1080 pixels; gfx950
 # correction of the guide applied: FETCH_SIZE counts 64 B per 128-B request -> x 2).  Counters cannot be read from
 # inside this process, so the per-launch figure reported below is this measured rate times the launch's pixels.
-MEASURED_HBM_BYTES_PER_PIXEL = (559662.0 * 1024 + 2 * 908.146 * 1024) / (64 * 1920 * 1080)
+MEASURED_HBM_BYTES_PER_PIXEL = (2238650.0 * 1024 + 2 * 3499.84 * 1024) / (256 * 1920 * 1080)
 
 
 def example1_soa():

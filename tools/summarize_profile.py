@@ -3,7 +3,7 @@ Usage: python tools/summarize_profile.py gpurun_out/r01 > profiles/r01_summary.m
 import csv, glob, os, sys, collections
 d = sys.argv[1]
 print(f"# rocprofv3 summary of `{d}`\n")
-print("Command profiled: `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline` (64 frames 1080p per launch)\n")
+print("Command profiled: `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline` (256 frames 1080p per launch)\n")
 for f in glob.glob(os.path.join(d, "kt", "**", "*kernel_stats.csv"), recursive=True):
     print("## kernel-trace --stats\n\n| kernel | calls | avg ns | min ns | max ns | % |\n|---|---|---|---|---|---|")
     for r in csv.DictReader(open(f)):
