@@ -106,8 +106,8 @@ def cpu_baseline_js(seconds=8.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)      # (the chip needs several launches to reach its clocks)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="after timing, compare rank 0's gathered frame 0 with a single-GPU render")
