@@ -1,6 +1,7 @@
 """Soak test (GPU): hybrid mode against the float64 kernel on many random few-sphere scenes, cameras and frame sizes.
 The float64 kernel is pinned to the CPU oracle and the reference's golden frames by tests/; this script looks for pixels
-where an error bound of the float32 kernel is too tight (any difference is a bug).  Usage: python tools/soak_hybrid.py [scenes] [seed]"""
+where an error bound of the float32 kernel is too tight (any difference is a bug).  Usage: python tools/soak_hybrid.py [scenes] [seed] [max_spheres = 12]
+(more than 12 spheres: the two-level kernel of ptr_kernels_many.hip)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "path-tracer_amd", "py")]
@@ -9,10 +10,11 @@ import ptr_amd
 
 n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+max_n = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 r = ptr_amd.Renderer(0)
 bad_total = px_total = redo_total = 0
 for t in range(n_scenes):
-    n = int(rng.integers(1, 13))
+    n = int(rng.integers(1, max_n + 1))
     kind = t % 5
     soa = np.zeros((12, n))
     spread = (12, 3, 40)[kind % 3]
