@@ -177,6 +177,8 @@ int ptr_render(ptr_ctx *ctx, const ptr_params *p, uint32_t *out_rgba8, float *ou
 
 /* Same work, but outputs are DEVICE pointers (e.g. a torch tensor's data_ptr) and the call only
  * enqueues on `stream` (a hipStream_t, NULL = the context's own stream) without synchronising.
+ * Calls on one context may use different streams and may follow ptr_set_* calls without a host wait in between: the
+ * library orders a call's kernels, and a scene upload, behind the kernels of the context's previous call.
  * Renders frames [first_frame, first_frame+n_frames) of the uploaded sequence back to back into
  * d_rgba8 (n_frames * width * scan_height uint32) with one launch per kernel.
  * This is the entry bench.py times: inputs resident in HBM, outputs left in HBM.              */
@@ -202,7 +204,9 @@ int ptr_render_strips_device(ptr_ctx *ctx, const ptr_params *p, const ptr_strips
                              int first_frame, int n_frames, void *d_rgba8, void *d_rgba32f,
                              uint64_t frame_stride_px, void *stream);
 
-/* Block until everything enqueued on the context's own stream has finished.                   */
+/* Block until everything enqueued on the context's own stream has finished.  Also uploads a scene, background or
+ * camera that was set since the last render (the render calls otherwise do that on their first use).  Work enqueued on
+ * a caller's stream is the caller's to wait for.                                               */
 int ptr_sync(ptr_ctx *ctx);
 
 /* ---- single rays ------------------------------------------------------------------------- */

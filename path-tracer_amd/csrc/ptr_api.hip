@@ -23,7 +23,7 @@ using namespace ptr;
 
 namespace {
 
-thread_local std::string g_create_error = "";
+thread_local char g_create_error[512] = "";      // fixed buffers: reporting an error must never throw
 
 struct DeviceBuffer {
     void*  ptr = nullptr;
@@ -43,7 +43,7 @@ struct ptr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::mutex mu;
-    std::string err;
+    char err[512] = "";
 
     // host copy of the scene sequence (float64, C-ABI plane order)
     std::vector<double> soa;
@@ -71,18 +71,22 @@ struct ptr_ctx {
     std::vector<unsigned char> host_blocks;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // PTR_FLAG_TIMING
     int timed_kernels = 0;             // kernels bracketed by ev[] in the last timed call
+    // The device-pointer entry points only enqueue, on the caller's stream: last_ev marks the end of the most recent
+    // call's kernels, so that a later call on another stream, a scene upload or ptr_get_stats can order itself behind them.
+    hipEvent_t last_ev = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool have_last = false;
+    unsigned char* stats_words = nullptr;   // where the last call's kernels put their stats words
 };
 
 namespace {
 
 int fail(ptr_ctx* c, int code, const char* fmt, ...)
 {
-    char buf[512];
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
+    vsnprintf(c ? c->err : g_create_error, 512, fmt, ap);
     va_end(ap);
-    if (c) c->err = buf; else g_create_error = buf;
     return code;
 }
 
@@ -268,21 +272,44 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
     return needs_exact;
 }
 
-// rebuild + upload the frame blocks if scene, background or camera changed
-int ensure_uploaded(ptr_ctx* c)
+// make stream s wait for the kernels of the context's most recent call, if that call went to another stream
+int order_after_last(ptr_ctx* c, hipStream_t s)
+{
+    if (c->have_last && c->last_stream != s) HIP_TRY(c, hipStreamWaitEvent(s, c->last_ev, 0));
+    return PTR_OK;
+}
+
+int mark_launch(ptr_ctx* c, hipStream_t s)
+{
+    HIP_TRY(c, hipEventRecord(c->last_ev, s));
+    c->last_stream = s;
+    c->have_last = true;
+    return PTR_OK;
+}
+
+// Rebuild + upload the frame blocks if scene, background or camera changed.  The copy goes onto the stream the kernels
+// will be launched on, so it is ordered behind the kernels of earlier calls that may still be reading the old blocks
+// (the device-pointer entry points do not wait for their kernels), and the host waits for it: host_blocks is rebuilt in
+// place by the next upload.
+int ensure_uploaded(ptr_ctx* c, hipStream_t s)
 {
     if (!c->dirty) return PTR_OK;
     const BlockLayout L = block_layout(c->n_spheres);
-    c->host_blocks.resize(L.bytes * (size_t)c->n_frames);
+    try {
+        c->host_blocks.resize(L.bytes * (size_t)c->n_frames);
+    } catch (const std::bad_alloc&) {
+        return fail(c, PTR_ERR_INVALID, "out of host memory building the frame blocks");
+    }
     bool ne = false;
     for (int f = 0; f < c->n_frames; f++)
         ne |= build_frame_block(c->host_blocks.data() + L.bytes * (size_t)f, L,
                                 c->soa.data() + (size_t)f * 12u * (size_t)c->n_spheres, c->n_spheres,
                                 c->bg, c->cam.origin);
-    PTR_TRY(grow(c, c->scenes, c->host_blocks.size()));
+    PTR_TRY(order_after_last(c, s));
+    PTR_TRY(grow(c, c->scenes, c->host_blocks.size()));          // (a hipFree waits for the whole device)
     HIP_TRY(c, hipMemcpyAsync(c->scenes.ptr, c->host_blocks.data(), c->host_blocks.size(),
-                              hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                              hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
     c->frame_stride = L.bytes;
     c->needs_exact = ne;
     c->dirty = false;
@@ -342,7 +369,8 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
                    uint32_t* d_out8, float* d_out32f, hipStream_t s,
                    const ptr_strips* strips = nullptr, uint64_t frame_stride_px = 0)
 {
-    PTR_TRY(ensure_uploaded(c));
+    PTR_TRY(order_after_last(c, s));          // queue, counters and stats words are shared by all calls on the context
+    PTR_TRY(ensure_uploaded(c, s));
     PTR_TRY(ensure_words(c, s));
 
     RenderArgs a;
@@ -377,6 +405,7 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
     a.camf.ox = (float)(-a.cam.angle * a.cam.aspect);
     a.camf.sy = (float)(-2.0 * a.cam.inv_h * a.cam.angle);
     a.camf.oy = (float)(a.cam.angle);
+    bool cam_exact = false;
     {
         // Tile culling of the float32 kernel: a wave's pixels are a 16 x 8 block of the image when its 8 local rows
         // are consecutive image rows.  Unnormalised directions D = xx R + yy U + F differ from the tile centre's by at
@@ -392,14 +421,26 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
         a.cull_on = (rows_consecutive && sn < 0.5) ? 1 : 0;
         a.cull_sin = (float)(sn * (1.0 + 1e-6));
         a.cull_cos = (float)(std::sqrt(std::fmax(0.0, 1.0 - sn * sn)) * (1.0 - 1e-6));
+        // The float32 error budget of the hit tests (PR_RELB: 10 eps for b = l.d) counts on a camera ray that is good to
+        // about one eps, which is what xx R + yy U + F gives while its terms are of the size of the sum: the direction's
+        // relative error grows like g = (|xx|max |R| + |yy|max |U| + |F|) / dmin (1.7 for the reference camera at 16:9;
+        // measured 1.1 eps there, 3.3 eps at g = 10-11: fov 150 degrees, or aspect 32).  Wide or skewed cameras beyond
+        // g = 4 are rendered in float64 rather than trusted to the budget.
+        const double g = dmin > 0 ? (std::fabs(a.cam.angle * a.cam.aspect) * std::sqrt(R[0] * R[0] + R[1] * R[1] + R[2] * R[2]) +
+                                     std::fabs(a.cam.angle) * std::sqrt(U[0] * U[0] + U[1] * U[1] + U[2] * U[2]) +
+                                     std::sqrt(F[0] * F[0] + F[1] * F[1] + F[2] * F[2])) / dmin : 1e300;
+        cam_exact = !(g <= 4.0);
     }
     a.out8 = d_out8;
     a.out32f = d_out32f;
     unsigned char* words = static_cast<unsigned char*>(c->words.ptr);
     a.stats = reinterpret_cast<unsigned long long*>(words + WORDS_STATS);
+    c->stats_words = words + WORDS_STATS;
 
     const bool stats = (p->flags & PTR_FLAG_STATS) != 0;
-    const bool exact = stats || (p->flags & PTR_MODE_EXACT_F64) || c->needs_exact;
+    // (PTR_MODE_F32_ONLY is the caller's explicit choice of float32 whatever the camera)
+    const bool exact = stats || (p->flags & PTR_MODE_EXACT_F64) || c->needs_exact ||
+                       (cam_exact && !(p->flags & PTR_MODE_F32_ONLY) && p->max_depth == 0 && p->spp == 1);
     const bool timing = (p->flags & PTR_FLAG_TIMING) != 0;
     if (stats) HIP_TRY(c, hipMemsetAsync(words + WORDS_STATS, 0, 256, s));
     if (timing) {
@@ -414,18 +455,18 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
         a.max_depth = p->max_depth; a.spp = p->spp; a.seed = p->seed;
         HIP_TRY(c, launch_render_ext(a, n_frames, exact, stats, s));
         if (timing) { HIP_TRY(c, hipEventRecord(c->ev[1], s)); c->timed_kernels = 1; }
-        return PTR_OK;
+        return mark_launch(c, s);
     }
     if (exact) {
         HIP_TRY(c, launch_render_exact(a, n_frames, stats, s));
         if (timing) { HIP_TRY(c, hipEventRecord(c->ev[1], s)); c->timed_kernels = 1; }
-        return PTR_OK;
+        return mark_launch(c, s);
     }
     const bool many = c->n_spheres > PTR_FAST_MAX_SPHERES || (p->flags & PTR_DEBUG_FORCE_MANY);
     if (p->flags & PTR_MODE_F32_ONLY) {
         HIP_TRY(c, many ? launch_render_many(a, n_frames, false, s) : launch_render_fast(a, n_frames, false, s));
         if (timing) { HIP_TRY(c, hipEventRecord(c->ev[1], s)); c->timed_kernels = 1; }
-        return PTR_OK;
+        return mark_launch(c, s);
     }
     // hybrid: float32 kernel fills the sub-queues, float64 kernel drains them
     const int rpb = many ? many_kernel_rows_per_block() : fast_kernel_rows_per_block();
@@ -456,7 +497,7 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
         c->words_dirty = true;
         return fail(c, PTR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     }
-    return PTR_OK;
+    return mark_launch(c, s);
 }
 
 int set_scene_locked(ptr_ctx* c, const double* soa, int n, int n_frames)
@@ -486,7 +527,7 @@ int ptr_abi_version(void) { return PTR_ABI_VERSION; }
 
 const char* ptr_last_error(ptr_ctx* ctx)
 {
-    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+    return ctx ? ctx->err : g_create_error;
 }
 
 int ptr_create(int device, ptr_ctx** out)
@@ -520,6 +561,13 @@ int ptr_create(int device, ptr_ctx** out)
         delete c;
         return fail(nullptr, PTR_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    e = hipEventCreateWithFlags(&c->last_ev, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        if (c->last_ev) (void)hipEventDestroy(c->last_ev);
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return fail(nullptr, PTR_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e));
+    }
     *out = c;
     return PTR_OK;
 }
@@ -529,12 +577,14 @@ void ptr_destroy(ptr_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+    if (c->have_last) (void)hipEventSynchronize(c->last_ev);     // kernels enqueued on a caller's stream still read our buffers
     for (DeviceBuffer* b : {&c->scenes, &c->queue, &c->words, &c->out8, &c->out32f, &c->tr_in_o,
                             &c->tr_in_d, &c->tr_rgb, &c->tr_el, &c->tr_hit, &c->tr_nrm, &c->rc_depth, &c->rc_keys,
                             &c->rc_temp, &c->rc_hit, &c->rc_age, &c->rc_item, &c->rc_pel, &c->rc_pdep, &c->rc_rgb,
                             &c->rc_prgb, &c->rc_pprio, &c->rc_hist, &c->rc_frames, &c->rc_page})
         if (b->ptr) (void)hipFree(b->ptr);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->last_ev) (void)hipEventDestroy(c->last_ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -556,7 +606,13 @@ int ptr_set_scene(ptr_ctx* c, const float* soa, int n_spheres)
     if (!c) return PTR_ERR_INVALID;
     if (n_spheres < 0) { std::lock_guard<std::mutex> g(c->mu); return fail(c, PTR_ERR_INVALID, "n_spheres < 0"); }
     if (n_spheres > 0 && !soa) { std::lock_guard<std::mutex> g(c->mu); return fail(c, PTR_ERR_INVALID, "soa is NULL"); }
-    std::vector<double> tmp((size_t)12 * (size_t)n_spheres);
+    std::vector<double> tmp;
+    try {
+        tmp.resize((size_t)12 * (size_t)n_spheres);
+    } catch (const std::bad_alloc&) {
+        std::lock_guard<std::mutex> g(c->mu);
+        return fail(c, PTR_ERR_INVALID, "out of host memory copying the scene");
+    }
     for (size_t k = 0; k < tmp.size(); k++) tmp[k] = (double)soa[k];
     return ptr_set_scene_sequence_f64(c, tmp.data(), n_spheres, 1);
 }
@@ -657,6 +713,7 @@ int ptr_sync(ptr_ctx* c)
     if (!c) return PTR_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->have_scene) PTR_TRY(ensure_uploaded(c, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return PTR_OK;
 }
@@ -694,7 +751,7 @@ static int trace_batch_locked(ptr_ctx* c, const double* origins, const double or
     if (n == 0) return PTR_OK;
     if (!dirs || !out_rgb) return fail(c, PTR_ERR_INVALID, "dirs_xyz / out_rgb64 is NULL");
     HIP_TRY(c, hipSetDevice(c->device));
-    PTR_TRY(ensure_uploaded(c));
+    PTR_TRY(ensure_uploaded(c, c->stream));
     const size_t v3 = (size_t)n * 3 * sizeof(double);
     PTR_TRY(grow(c, c->tr_in_d, v3));
     PTR_TRY(grow(c, c->tr_rgb, v3));
@@ -763,10 +820,16 @@ int ptr_trace_batch(ptr_ctx* c, const float* dirs_xyz, int n,
         return fail(c, PTR_ERR_INVALID, "bad arguments to ptr_trace_batch");
     }
     if (n == 0) return PTR_OK;
-    std::vector<double> d((size_t)n * 3), rgb((size_t)n * 3), hit, nrm;
+    std::vector<double> d, rgb, hit, nrm;
+    try {
+        d.resize((size_t)n * 3); rgb.resize((size_t)n * 3);
+        if (out_hit_xyz) hit.resize((size_t)n * 3);
+        if (out_normal_xyz) nrm.resize((size_t)n * 3);
+    } catch (const std::bad_alloc&) {
+        std::lock_guard<std::mutex> g(c->mu);
+        return fail(c, PTR_ERR_INVALID, "out of host memory in ptr_trace_batch");
+    }
     for (size_t k = 0; k < d.size(); k++) d[k] = (double)dirs_xyz[k];
-    if (out_hit_xyz) hit.resize((size_t)n * 3);
-    if (out_normal_xyz) nrm.resize((size_t)n * 3);
     PTR_TRY(ptr_trace_batch_f64(c, nullptr, d.data(), n, rgb.data(), nullptr,
                                 out_hit_xyz ? hit.data() : nullptr, out_normal_xyz ? nrm.data() : nullptr));
     for (size_t k = 0; k < rgb.size(); k++)     // RayTracer.js:105-112
@@ -984,11 +1047,12 @@ int ptr_get_stats(ptr_ctx* c, ptr_stats* out)
     std::lock_guard<std::mutex> g(c->mu);
     if (!out) return fail(c, PTR_ERR_INVALID, "out is NULL");
     std::memset(out, 0, sizeof *out);
-    if (!c->words.ptr) return PTR_OK;
+    if (!c->stats_words) return PTR_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // the last call's kernels may have gone to a caller's stream without anybody waiting for them yet
+    if (c->have_last) HIP_TRY(c, hipEventSynchronize(c->last_ev));
     unsigned long long w[9];
-    HIP_TRY(c, hipMemcpy(w, static_cast<unsigned char*>(c->words.ptr) + WORDS_STATS, sizeof w, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(w, c->stats_words, sizeof w, hipMemcpyDeviceToHost));
     out->primary = w[0]; out->hits = w[1]; out->shadow_rays = w[2];
     out->exit_tca = w[3]; out->exit_d2 = w[4]; out->exit_hit = w[5]; out->retraced = w[6]; out->reshaded = w[7]; out->secondary = w[8];
     return PTR_OK;

@@ -51,8 +51,11 @@ static void finalize_ctx(napi_env env, void *data, void *hint)
     ptr_destroy((ptr_ctx *)data);          /* the GC owns handles that were never destroy()ed */
 }
 
-/* handles are napi externals whose data pointer is cleared by destroy() via a wrapper cell */
-typedef struct { ptr_ctx *ctx; } handle_cell;
+/* Handles are napi externals whose data pointer is cleared by destroy() via a wrapper cell.  renderAsync jobs run
+ * ptr_render on a libuv worker thread: while any is in flight (`jobs`) a destroy() only marks the handle dead
+ * (`closing`) and the last job's completion callback destroys the context.  Both fields are touched on the JavaScript
+ * thread only (destroy(), the job's start and its completion callback all run there).                              */
+typedef struct { ptr_ctx *ctx; int jobs; int closing; } handle_cell;
 
 static void finalize_cell(napi_env env, void *data, void *hint)
 {
@@ -64,7 +67,7 @@ static void finalize_cell(napi_env env, void *data, void *hint)
 static ptr_ctx *get_ctx(napi_env env, napi_value v)
 {
     handle_cell *cell = NULL;
-    if (napi_get_value_external(env, v, (void **)&cell) != napi_ok || !cell || !cell->ctx) {
+    if (napi_get_value_external(env, v, (void **)&cell) != napi_ok || !cell || !cell->ctx || cell->closing) {
         napi_throw_type_error(env, NULL, "not a live renderer handle");
         return NULL;
     }
@@ -131,7 +134,7 @@ static napi_value js_create(napi_env env, napi_callback_info info)
     if (rc != PTR_OK) return throw_ptr(env, NULL, rc);
     handle_cell *cell = (handle_cell *)malloc(sizeof *cell);
     if (!cell) { ptr_destroy(ctx); napi_throw_error(env, NULL, "out of memory"); return NULL; }
-    cell->ctx = ctx;
+    cell->ctx = ctx; cell->jobs = 0; cell->closing = 0;
     napi_value h;
     if (napi_create_external(env, cell, finalize_cell, NULL, &h) != napi_ok) {
         ptr_destroy(ctx); free(cell);
@@ -147,8 +150,12 @@ static napi_value js_destroy(napi_env env, napi_callback_info info)
     if (!get_args(env, info, 1, argv)) return NULL;
     handle_cell *cell = NULL;
     if (napi_get_value_external(env, argv[0], (void **)&cell) == napi_ok && cell && cell->ctx) {
-        ptr_destroy(cell->ctx);
-        cell->ctx = NULL;
+        if (cell->jobs > 0) {
+            cell->closing = 1;             /* a worker thread is inside ptr_render: render_complete destroys */
+        } else {
+            ptr_destroy(cell->ctx);
+            cell->ctx = NULL;
+        }
     }
     return NULL;
 }
@@ -272,7 +279,8 @@ typedef struct {
     char err[512];
     napi_deferred deferred;
     napi_async_work work;
-    napi_ref handle_ref;        /* keeps the renderer alive while the job runs */
+    napi_ref handle_ref;        /* keeps the handle from being collected while the job runs */
+    handle_cell *cell;          /* ... and this keeps an explicit destroy() from freeing the context under it */
 } render_job;
 
 static void render_execute(napi_env env, void *data)
@@ -308,6 +316,11 @@ static void render_complete(napi_env env, napi_status status, void *data)
         napi_create_error(env, NULL, msg, &err);
         napi_reject_deferred(env, j->deferred, err);
     }
+    if (--j->cell->jobs == 0 && j->cell->closing && j->cell->ctx) {
+        ptr_destroy(j->cell->ctx);         /* destroy() was called while this job ran */
+        j->cell->ctx = NULL;
+        j->cell->closing = 0;
+    }
     napi_delete_reference(env, j->handle_ref);
     napi_delete_async_work(env, j->work);
     free(j->pixels);
@@ -323,6 +336,7 @@ static napi_value js_render_async(napi_env env, napi_callback_info info)
     render_job *j = (render_job *)calloc(1, sizeof *j);
     if (!j) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
     j->ctx = ctx;
+    if (napi_get_value_external(env, argv[0], (void **)&j->cell) != napi_ok || !j->cell) { free(j); return NULL; }
     if (!read_params(env, argv + 1, &j->p) || !check_frame_size(env, &j->p)) { free(j); return NULL; }
     j->pixels = (uint32_t *)malloc((size_t)j->p.width * (size_t)j->p.scan_height * 4);
     if (!j->pixels) { free(j); napi_throw_error(env, NULL, "out of memory"); return NULL; }
@@ -336,6 +350,7 @@ static napi_value js_render_async(napi_env env, napi_callback_info info)
         napi_throw_error(env, NULL, "could not start the async render");
         return NULL;
     }
+    j->cell->jobs++;
     return promise;
 }
 

@@ -388,6 +388,16 @@ async function gpuTests() {
         assert.ok(sameBytes(Buffer.from(second[3].buf8), new Uint8Array(ref.render(320, 240, 90, 30))));
         ref.dispose(); planner.dispose();
     });
+    await atest('dispose() right after renderAsync(): the job in flight finishes on a live context', async () => {
+        const m = index.frames['example1@160x120'];
+        for (let round = 0; round < 4; round++) {
+            const rt = new RayTracer(new Vector3(2, 2, 2), buildExample1());
+            const pending = [rt.renderAsync(m.width, m.height), rt.renderAsync(m.width, m.height)];
+            rt.dispose();                                     // the worker threads are (or will be) inside ptr_render
+            assert.throws(() => rt.render(8, 8), /disposed/);
+            for (const buf of await Promise.all(pending)) assert.ok(sameBytes(new Uint8Array(buf), u8(m.file)));
+        }
+    });
     test('stats(): the reference ray mix at 640x480 (SURVEY 6)', () => {
         const rt = new RayTracer(new Vector3(2, 2, 2), buildExample1());
         rt.render(640, 480);

@@ -200,3 +200,76 @@ def test_strips_with_whole_tiles_use_the_culling_path(rdr, scenes, n_parts, stri
         torch.cuda.synchronize()
         full[rows] = buf.cpu().numpy().view(np.uint32)[: len(rows)]
     assert np.array_equal(full, want)
+
+
+def test_scene_change_between_enqueued_calls_without_a_host_wait(scenes):
+    """set_scene, render_device(stream), set_scene, render_device(stream) with no synchronisation in between: the second
+    upload is ordered behind the first call's kernels, so neither frame is torn (the upload used to go to the
+    context's own stream while the kernels ran on the caller's)"""
+    torch = pytest.importorskip("torch")
+    sc = scenes["example1"]
+    a = ptr_amd.scene_to_soa(sc["elements"])
+    b = a.copy(); b[1, 1:5] += 3.0; b[0, 2] = -1.0
+    w, h, nf = 1920, 1080, 6                       # long enough that the first call is still running at the second upload
+    r = ptr_amd.Renderer(0)
+    try:
+        r.set_background(sc["background"])
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        out = [torch.empty((nf, h, w), dtype=torch.int32, device="cuda") for _ in range(3)]
+        p = r.params(w, h, flags=0)
+        r.set_scene(np.stack([a] * nf))
+        r.render_device(p, 0, nf, out[0].data_ptr(), stream=s1.cuda_stream)
+        r.set_scene(np.stack([b] * nf))
+        r.render_device(p, 0, nf, out[1].data_ptr(), stream=s1.cuda_stream)
+        r.set_scene(np.stack([a] * nf))            # ... and across streams
+        r.render_device(p, 0, nf, out[2].data_ptr(), stream=s2.cuda_stream)
+        torch.cuda.synchronize()
+        want_a = orc.render(a, sc["background"], w, h, flags=0).reshape(h, w)
+        want_b = orc.render(b, sc["background"], w, h, flags=0).reshape(h, w)
+        for k, want in enumerate((want_a, want_b, want_a)):
+            got = out[k].cpu().numpy().view(np.uint32)
+            for f in range(nf):
+                assert np.array_equal(got[f], want), (k, f)
+        # stats of a call on a caller's stream: ptr_get_stats waits for that call's kernels itself
+        r.render_device(r.params(w, h, flags=ptr_amd.FLAG_STATS), 0, 1, out[0].data_ptr(), stream=s2.cuda_stream)
+        assert r.stats()["primary"] == w * h
+        torch.cuda.synchronize()
+    finally:
+        r.close()
+
+
+def test_wide_and_skewed_cameras_render_the_reference_bytes(scenes):
+    """fov 120-150 degrees, aspect 16 and a scaled, non-orthogonal basis: the float32 ray of such cameras is outside the
+    hybrid mode's error budget, the default mode must still give the float64 bytes"""
+    import math
+    sc = scenes["example1"]
+    soa = ptr_amd.scene_to_soa(sc["elements"])
+    r = ptr_amd.Renderer(0)
+    try:
+        r.set_scene(soa); r.set_background(sc["background"])
+        cases = [
+            dict(w=320, h=180, fov=90, right=(1, 0, 0), up=(0, 1, 0), forward=(0, 0, -1)),        # stays hybrid
+            dict(w=320, h=180, fov=150, right=(1, 0, 0), up=(0, 1, 0), forward=(0, 0, -1)),
+            dict(w=640, h=40, fov=30, right=(1, 0, 0), up=(0, 1, 0), forward=(0, 0, -1)),         # aspect 16
+            dict(w=200, h=120, fov=120, right=(37.0, 0, 3.0), up=(0.5, 41.0, 0), forward=(0.2, -0.1, -39.0)),
+        ]
+        for c in cases:
+            t = math.tan(math.pi * 0.5 * c["fov"] / 180)
+            r.set_camera(origin=(0.5, 1.0, 2.0), right=c["right"], up=c["up"], forward=c["forward"], tan_half_fov=t)
+            exact = r.render(c["w"], c["h"], flags=ptr_amd.MODE_EXACT_F64)
+            hybrid = r.render(c["w"], c["h"], flags=0)
+            assert np.array_equal(hybrid, exact), c
+            # the oracle's trace on the rays of RayTracer.js:171-174 (same operations, same order, vectorised)
+            w, h = c["w"], c["h"]
+            R, U, F = (np.array(c[k], dtype=np.float64) for k in ("right", "up", "forward"))
+            xs = (2 * ((np.arange(w) + 0.5) * (1 / w)) - 1) * t * (w / h)
+            ys = (1 - 2 * ((np.arange(h) + 0.5) * (1 / h))) * t
+            xx, yy = np.meshgrid(xs, ys)
+            d = [xx * R[k] + yy * U[k] + F[k] for k in range(3)]
+            inv = 1 / np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])
+            dirs = np.stack([d[k] * inv for k in range(3)], axis=-1).reshape(-1, 3)
+            rgb = orc.trace_batch(soa, np.array(sc["background"], dtype=np.float64), np.tile([0.5, 1.0, 2.0], (w * h, 1)), dirs)[0]
+            want = np.array([orc.pack(v) for v in rgb], dtype=np.uint32)
+            assert np.array_equal(exact, want), c
+    finally:
+        r.close()
