@@ -204,6 +204,22 @@ int ptr_render_strips_device(ptr_ctx *ctx, const ptr_params *p, const ptr_strips
                              int first_frame, int n_frames, void *d_rgba8, void *d_rgba32f,
                              uint64_t frame_stride_px, void *stream);
 
+/* ptr_render_device for callers that cannot allocate.  No counterpart in the reference: it exists for callers that
+ * may not call hipMalloc at this point - code under HIP graph capture, tight serving loops, harnesses that forbid it.
+ * Same arguments, same kernels and the same output bytes as ptr_render_device, but the call allocates nothing (no
+ * hipMalloc / hipFree / event creation, in any mode): the float32 kernels' re-trace queue, its counters and the work
+ * counters live in a 32 MiB array that is part of the library's code object, one copy per GPU, held until the process
+ * ends.  Limits and rules:
+ *   - the hybrid mode needs 12 bytes of queue per pixel of the call's tiles: about 2.6 M pixels per call at most (one
+ *     1920x1080 frame fits; width * scan_height * n_frames beyond that returns PTR_ERR_INVALID, nothing is launched);
+ *   - the scene must already be resident: call ptr_sync() after the last ptr_set_scene* / ptr_set_background* /
+ *     ptr_set_camera (the upload is what allocates); otherwise PTR_ERR_INVALID;
+ *   - PTR_FLAG_TIMING is rejected (it creates events); PTR_FLAG_STATS works;
+ *   - all contexts on one GPU share the array, and every call clears the part that must start at zero: two such calls
+ *     that overlap in time on one GPU (different streams or contexts) race; calls on one stream are safe back to back. */
+int ptr_render_device_noalloc(ptr_ctx *ctx, const ptr_params *p, int first_frame, int n_frames,
+                              void *d_rgba8, void *d_rgba32f /* nullable */, void *stream);
+
 /* Block until everything enqueued on the context's own stream has finished.  Also uploads a scene, background or
  * camera that was set since the last render (the render calls otherwise do that on their first use).  Work enqueued on
  * a caller's stream is the caller's to wait for.                                               */

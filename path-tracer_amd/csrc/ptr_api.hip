@@ -37,6 +37,14 @@ constexpr size_t WORDS_COUNTER_B = WORDS_COUNTERS;
 constexpr size_t WORDS_STATS     = 2 * WORDS_COUNTERS;     // 8 x uint64
 constexpr size_t WORDS_BYTES     = WORDS_STATS + 256;
 
+// ptr_render_device_noalloc: the same words and the re-trace queue, in an array that belongs to the code object instead of
+// coming from hipMalloc.  Every GPU the library runs on holds its own copy (32 MiB) from the moment the library is loaded;
+// all contexts on one GPU share that copy.  Host code never uses the array's name as an address: ptr_create asks for this
+// GPU's address once (hipGetSymbolAddress) and everything below works with that pointer.
+constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t)32 << 20;
+constexpr size_t NOALLOC_QUEUE_OFFSET  = (WORDS_BYTES + 255) / 256 * 256;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
 }  // namespace
 
 struct ptr_ctx {
@@ -77,6 +85,7 @@ struct ptr_ctx {
     hipStream_t last_stream = nullptr;
     bool have_last = false;
     unsigned char* stats_words = nullptr;   // where the last call's kernels put their stats words
+    unsigned char* scratch_dev = nullptr;   // this GPU's address of the static array `scratch`
 };
 
 namespace {
@@ -364,14 +373,26 @@ int ensure_words(ptr_ctx* c, hipStream_t s)
     return PTR_OK;
 }
 
-// enqueue the kernels of one render call; no synchronisation
+// Enqueue the kernels of one render call; no synchronisation.  fixed_ws: the kernels' words and re-trace queue come from
+// the static array (ptr_render_device_noalloc) and nothing in here allocates; otherwise from the context's own buffers,
+// grown on demand.
 int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frames,
                    uint32_t* d_out8, float* d_out32f, hipStream_t s,
-                   const ptr_strips* strips = nullptr, uint64_t frame_stride_px = 0)
+                   const ptr_strips* strips = nullptr, uint64_t frame_stride_px = 0, bool fixed_ws = false)
 {
     PTR_TRY(order_after_last(c, s));          // queue, counters and stats words are shared by all calls on the context
-    PTR_TRY(ensure_uploaded(c, s));
-    PTR_TRY(ensure_words(c, s));
+    if (fixed_ws) {
+        if (c->dirty)
+            return fail(c, PTR_ERR_INVALID, "ptr_render_device_noalloc: the scene is not resident on the GPU yet; call "
+                                            "ptr_sync() after the last ptr_set_* call (the upload allocates)");
+        if (p->flags & PTR_FLAG_TIMING)
+            return fail(c, PTR_ERR_INVALID, "ptr_render_device_noalloc: PTR_FLAG_TIMING is not available (it creates events)");
+        // every call on this GPU shares the array and finds the last call's contents in it: clear what must start at zero
+        HIP_TRY(c, hipMemsetAsync(c->scratch_dev, 0, WORDS_BYTES, s));
+    } else {
+        PTR_TRY(ensure_uploaded(c, s));
+        PTR_TRY(ensure_words(c, s));
+    }
 
     RenderArgs a;
     std::memset(&a, 0, sizeof a);
@@ -433,7 +454,7 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
     }
     a.out8 = d_out8;
     a.out32f = d_out32f;
-    unsigned char* words = static_cast<unsigned char*>(c->words.ptr);
+    unsigned char* words = fixed_ws ? c->scratch_dev : static_cast<unsigned char*>(c->words.ptr);
     a.stats = reinterpret_cast<unsigned long long*>(words + WORDS_STATS);
     c->stats_words = words + WORDS_STATS;
 
@@ -442,7 +463,7 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
     const bool exact = stats || (p->flags & PTR_MODE_EXACT_F64) || c->needs_exact ||
                        (cam_exact && !(p->flags & PTR_MODE_F32_ONLY) && p->max_depth == 0 && p->spp == 1);
     const bool timing = (p->flags & PTR_FLAG_TIMING) != 0;
-    if (stats) HIP_TRY(c, hipMemsetAsync(words + WORDS_STATS, 0, 256, s));
+    if (stats && !fixed_ws) HIP_TRY(c, hipMemsetAsync(words + WORDS_STATS, 0, 256, s));
     if (timing) {
         for (auto& e : c->ev)
             if (!e) HIP_TRY(c, hipEventCreate(&e));
@@ -477,16 +498,28 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
     while (n_queues * 2 <= PTR_MAX_QUEUES && n_queues * 8 <= n_blocks) n_queues *= 2;
     // a workgroup can queue at most PTR_BLOCK pixels; sub-queue s serves the workgroups b with (b & (n_queues - 1)) == s
     const uint64_t sub_capacity = (n_blocks + n_queues - 1) / n_queues * (uint64_t)(cpb * rpb);
-    PTR_TRY(grow(c, c->queue, (size_t)(n_queues * sub_capacity) * 3 * sizeof(uint32_t)));   // ids + 2 info words
-    const bool odd = (c->hybrid_calls & 1u) != 0;
-    a.queue = static_cast<uint32_t*>(c->queue.ptr);
+    const size_t queue_bytes = (size_t)(n_queues * sub_capacity) * 3 * sizeof(uint32_t);   // ids + 2 info words
+    if (fixed_ws) {
+        if (queue_bytes > NOALLOC_SCRATCH_BYTES - NOALLOC_QUEUE_OFFSET)
+            return fail(c, PTR_ERR_INVALID, "ptr_render_device_noalloc: this call needs a re-trace queue of %zu bytes (12 per "
+                                            "pixel of its tiles), the static array holds %zu: render fewer pixels per call "
+                                            "(about 2.6 M at most), or use ptr_render_device",
+                        queue_bytes, NOALLOC_SCRATCH_BYTES - NOALLOC_QUEUE_OFFSET);
+    } else {
+        PTR_TRY(grow(c, c->queue, queue_bytes));
+    }
+    // (the static array was cleared above: its calls always use counter set A)
+    const bool odd = !fixed_ws && (c->hybrid_calls & 1u) != 0;
+    a.queue = fixed_ws ? reinterpret_cast<uint32_t*>(c->scratch_dev + NOALLOC_QUEUE_OFFSET) : static_cast<uint32_t*>(c->queue.ptr);
     a.qinfo = a.queue + n_queues * sub_capacity;
     a.queue_capacity = (uint32_t)sub_capacity;
     a.n_queues = (uint32_t)n_queues;
     a.counter = reinterpret_cast<uint32_t*>(words + (odd ? WORDS_COUNTER_B : WORDS_COUNTER_A));
     a.counter_next = reinterpret_cast<uint32_t*>(words + (odd ? WORDS_COUNTER_A : WORDS_COUNTER_B));
-    c->hybrid_calls++;
-    HIP_TRY(c, hipMemsetAsync(words + WORDS_STATS, 0, 256, s));
+    if (!fixed_ws) {
+        c->hybrid_calls++;
+        HIP_TRY(c, hipMemsetAsync(words + WORDS_STATS, 0, 256, s));
+    }
     hipError_t e = many ? launch_render_many(a, n_frames, true, s) : launch_render_fast(a, n_frames, true, s);
     if (e == hipSuccess && timing) e = hipEventRecord(c->ev[1], s);
     if (e == hipSuccess) {
@@ -562,11 +595,13 @@ int ptr_create(int device, ptr_ctx** out)
         return fail(nullptr, PTR_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
     e = hipEventCreateWithFlags(&c->last_ev, hipEventDisableTiming);
-    if (e != hipSuccess) {
+    // this GPU's copy of the static array (the device is current): the address differs from GPU to GPU
+    if (e == hipSuccess) e = hipGetSymbolAddress(reinterpret_cast<void**>(&c->scratch_dev), HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !c->scratch_dev) {
         if (c->last_ev) (void)hipEventDestroy(c->last_ev);
         (void)hipStreamDestroy(c->stream);
         delete c;
-        return fail(nullptr, PTR_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e));
+        return fail(nullptr, PTR_ERR_HIP, "ptr_create: event / hipGetSymbolAddress(scratch): %s", hipGetErrorString(e));
     }
     *out = c;
     return PTR_OK;
@@ -668,6 +703,19 @@ int ptr_render_device(ptr_ctx* c, const ptr_params* p, int first_frame, int n_fr
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
     return enqueue_render(c, p, first_frame, n_frames, static_cast<uint32_t*>(d_rgba8),
                           static_cast<float*>(d_rgba32f), s);
+}
+
+int ptr_render_device_noalloc(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frames,
+                              void* d_rgba8, void* d_rgba32f, void* stream)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    PTR_TRY(check_params(c, p, first_frame, n_frames));
+    if (!d_rgba8) return fail(c, PTR_ERR_INVALID, "d_rgba8 is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    return enqueue_render(c, p, first_frame, n_frames, static_cast<uint32_t*>(d_rgba8),
+                          static_cast<float*>(d_rgba32f), s, nullptr, 0, /*fixed_ws=*/true);
 }
 
 int ptr_strip_rows(const ptr_strips* s, int height)

@@ -27,7 +27,7 @@ SYMBOLS = [
     "ptr_abi_version", "ptr_create", "ptr_destroy", "ptr_last_error",
     "ptr_set_scene", "ptr_set_scene_f64", "ptr_set_scene_sequence_f64",
     "ptr_set_background", "ptr_set_background_f64", "ptr_set_camera",
-    "ptr_render", "ptr_render_device", "ptr_render_strips_device", "ptr_strip_rows", "ptr_sync",
+    "ptr_render", "ptr_render_device", "ptr_render_device_noalloc", "ptr_render_strips_device", "ptr_strip_rows", "ptr_sync",
     "ptr_trace_batch", "ptr_trace_batch_f64", "ptr_trace_samples_f64", "ptr_rc_reproject", "ptr_rc_reproject_device", "ptr_rc_shade", "ptr_rc_shade_device", "ptr_get_stats", "ptr_get_kernel_ms",
 ]
 
@@ -123,6 +123,7 @@ def lib():
         L.ptr_set_camera.argtypes = [vp, C.POINTER(Camera)]
         L.ptr_render.argtypes = [vp, C.POINTER(Params), C.POINTER(C.c_uint32), fp]
         L.ptr_render_device.argtypes = [vp, C.POINTER(Params), C.c_int, C.c_int, vp, vp, vp]
+        L.ptr_render_device_noalloc.argtypes = [vp, C.POINTER(Params), C.c_int, C.c_int, vp, vp, vp]
         L.ptr_render_strips_device.argtypes = [vp, C.POINTER(Params), C.POINTER(Strips), C.c_int, C.c_int,
                                                vp, vp, C.c_uint64, vp]
         L.ptr_strip_rows.argtypes = [C.POINTER(Strips), C.c_int]
@@ -241,6 +242,13 @@ class Renderer:
                                               C.c_void_p(d_rgba8),
                                               C.c_void_p(d_rgba32f) if d_rgba32f else None,
                                               C.c_void_p(stream) if stream else None))
+
+    def render_device_noalloc(self, p, first_frame, n_frames, d_rgba8, d_rgba32f=None, stream=None):
+        """ptr_render_device_noalloc: same outputs as render_device, allocates nothing (scene must be resident: sync() first)."""
+        self._check(self._L.ptr_render_device_noalloc(self._h, C.byref(p), first_frame, n_frames,
+                                                      C.c_void_p(d_rgba8),
+                                                      C.c_void_p(d_rgba32f) if d_rgba32f else None,
+                                                      C.c_void_p(stream) if stream else None))
 
     def render_strips_device(self, p, part, first_frame, n_frames, d_rgba8, d_rgba32f=None, stream=None,
                              frame_stride_px=0):
