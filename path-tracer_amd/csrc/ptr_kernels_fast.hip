@@ -405,33 +405,30 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
             for (int p = 0; p < PPL; p++) m |= sh[p].open_m;
             return m == 0ull;
         };
-        // Phase 1 for one light, once per WAVE: the shadow rays of the wave's open lanes lie in a cone around one of
-        // them (axis = the first open lane's L, half-width dmax = the largest |L - axis| + error of L over the open
-        // lanes, found by a cross-lane max).  The line through the light along L can reach element j only if
-        // |a_j . L| >= thr_j (PairQ), and |a_j . L| <= |a_j . axis| + dmax: lane j tests element j against the cone, and
-        // the ballot is a wave-uniform bit per occluder, "some open lane may reach it".  One compare -> mask round
-        // trip per light instead of one per occluder.
-        auto cone_prefilter = [&](const float4 pq, const F3 cj) -> unsigned {
-            const unsigned long long o0 = sh[0].open_m;
-            const bool first = o0 != 0ull || PPL == 1;                       // wave-uniform
-            const Shade& sa = sh[first ? 0 : PPL - 1];
-            const int src = (int)__builtin_ctzll(first ? o0 : sa.open_m);
-            const float ax = readlane_f(sa.L.x, src), ay = readlane_f(sa.L.y, src), az = readlane_f(sa.L.z, src);
-            float dev = 0.0f;
-#pragma unroll
-            for (int p = 0; p < PPL; p++) {
-                const Shade& s = sh[p];
-                const float dx = s.L.x - ax, dy = s.L.y - ay, dz = s.L.z - az;
-                const float e = __builtin_amdgcn_sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx))) + s.eL;
-                dev = fmax_raw(dev, lane_of(s.open_m) ? e : 0.0f);
-            }
-            const float dmax = fmaf(wave_max(dev), 1.000001f, 1e-7f);       // rounding of the above
-            const float c = fmaf(pq.z, az, fmaf(pq.y, ay, pq.x * ax));
+        // Phase 1 for one light, once per WAVE, from the ball of shadow-ray origins alone: every origin (and every hit
+        // point) is within prad of pc, so every shadow ray towards a light at C points within
+        //   dmax = rho / (|C - pc| - rho),  rho = prad + rounding of C - pc,
+        // of the axis (C - pc) / |C - pc|  (|u/|u| - v/|v|| <= |u - v| / min(|u|, |v|)).  The line through the light
+        // along L can reach element j only if |a_j . L| >= thr_j (PairQ), and |a_j . L| <= |a_j . axis| + dmax: lane j tests
+        // element j against the cone, and the ballot is a wave-uniform bit per occluder, "some lane may reach it".  No
+        // per-light cross-lane maximum: the ball was found once, with the hit points.
+        const F3 lcj{cj.x - pcx, cj.y - pcy, cj.z - pcz};              // lane j: element j's centre from the ball's centre
+        const float lcn = __builtin_amdgcn_sqrtf(dot3(lcj, lcj)) * 1.000001f + 1e-6f;
+        const float pradp = prad * 1.000001f;
+        auto cone_prefilter = [&](const float4 pq, const F3 lpos, const float llnorm) -> unsigned {
+            const F3 u{lpos.x - pcx, lpos.y - pcy, lpos.z - pcz};
+            const float dd = dot3(u, u);
+            const float inv = rsq(fmax_raw(dd, 1e-30f));
+            const float dist = dd * inv;
+            const float rho = fmaf(8.0f * EPS, llnorm + dist, prad);       // + rounding of the light's position and of u
+            const float den = dist - rho;
+            // (a light inside or next to the ball: no cone worth the name, nothing is culled)
+            const float dmax = den > rho ? fmaf(rho * rcp(den), 1.000001f, 1e-6f) : 4.0f;
+            const F3 ax{u.x * inv, u.y * inv, u.z * inv};
+            const float c = fmaf(pq.z, ax.z, fmaf(pq.y, ax.y, pq.x * ax.x));
             // ... and element j lies BEHIND every shadow ray of the wave when tca = (C_j - origin) . L < 0 for all of
             // them (Sphere.js:18-19: tca < 0 is a miss wherever the origin is):  tca <= lcj.axis + |lcj| dmax + prad
-            const F3 lcj{cj.x - pcx, cj.y - pcy, cj.z - pcz};          // lane j: element j's centre from the ball's centre
-            const float lcn = __builtin_amdgcn_sqrtf(dot3(lcj, lcj)) * 1.000001f + 1e-6f;
-            const float tca_up = fmaf(lcn, dmax, dot3(lcj, F3{ax, ay, az})) + prad * 1.000001f;
+            const float tca_up = fmaf(lcn, dmax, dot3(lcj, ax)) + pradp;
             return (unsigned)(ballot(fabsf(c) + dmax >= pq.w) & ballot(tca_up >= 0.0f)) & ((1u << n) - 1u);  // thr carries 8 more eps of slack
         };
         // Phase 2: the full test for the occluders whose bit is set (next record requested before the current is used)
@@ -472,7 +469,7 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
             }
             if (!all_closed()) {
                 // every element but the light itself (RayTracer.js:76) and the one the whole wave stands on
-                unsigned need = cone_prefilter(pq, cj) & ~(1u << i);
+                unsigned need = cone_prefilter(pq, lpos, llnorm) & ~(1u << i);
                 shadow_bits(pairs, need);
             }
 #pragma unroll
