@@ -217,7 +217,14 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
         p.r2 = (float)r2;
         p.lnorm = (float)(lnorm * (1.0 + 2 * EPS32) + 2.1e-4);   // upper bound of |l| + shadow bias
         p.inv_r = (float)(1.0 / std::fmax(rad, 1e-30));
-        p.hed = (float)(10.0 * EPS32 * rad * lnorm + 2.0 * EPS32 * r2);
+        {
+            // half the error bound of disc' = r^2 - |l x d|^2: 10 eps r |l| + 2 eps r^2, with |l| as padded above, half an
+            // eps more on each term for the rounding of the record's own values, rounded up
+            const double hed = 10.5 * EPS32 * rad * (double)p.lnorm + 2.5 * EPS32 * r2;
+            float f = (float)hed;
+            if ((double)f < hed) f = std::nextafterf(f, INFINITY);
+            p.hed = f;
+        }
         p.refl = (float)pl(7, i); p.transp = (float)pl(8, i);
         p32[i] = p;
         SphereM32 m;
@@ -428,7 +435,7 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
     a.camf.oy = (float)(a.cam.angle);
     bool cam_exact = false;
     {
-        // Tile culling of the float32 kernel: a wave's pixels are a 16 x 8 block of the image when its 8 local rows
+        // Tile culling of the float32 kernel: a wave's pixels are a (8 PPL) x 8 block of the image when its 8 local rows
         // are consecutive image rows.  Unnormalised directions D = xx R + yy U + F differ from the tile centre's by at
         // most rho, and |D| >= dmin (distance of the image plane from the eye), so sin(angle) <= rho / dmin.
         const double* R = c->cam.right; const double* U = c->cam.up; const double* F = c->cam.forward;

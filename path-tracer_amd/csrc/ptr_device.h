@@ -15,7 +15,13 @@
 #define PTR_TILE_H 8
 #define PTR_BLOCK  256
 #define PTR_FAST_BLOCK 64     // few-sphere kernel: one wave per workgroup (no LDS, no barrier: a wave then starts wherever a slot is free)
-#define PTR_FAST_PPL 2            // pixels per lane in the float32 kernel (wave tile 16 x 8: the slots side by side)
+#ifndef PTR_FAST_PPL
+#define PTR_FAST_PPL 3            // pixels per lane in the float32 kernel (wave tile 24 x 8: the slots side by side); measured 2 / 3 / 4
+                                  //   pixels per lane at 7 / 6 / 4 waves per SIMD: 0.743 / 0.728 / 1.52 ms per 64 frames of 1080p
+#endif
+#ifndef PTR_FAST_WAVES
+#define PTR_FAST_WAVES 6          // waves per SIMD the float32 kernel's register allocation aims at (80 VGPRs)
+#endif
 #define PTR_MAX_QUEUES 1024       // sub-queues of the hybrid mode's re-trace queue
 #define PTR_MAX_PAIR_LIGHTS 64     // lights with a shadow pre-filter table (more lights: no culling for them)
 #define PTR_FAST_MAX_SPHERES 12    // up to this many spheres: ptr_kernels_fast.hip; more: ptr_kernels_many.hip (measured
@@ -140,7 +146,7 @@ struct RenderArgs {
     uint64_t  out_frame_stride;      // pixels between consecutive frames in out8 / out32f
     CameraArgs cam;
     CameraF32  camf;
-    float     cull_cos, cull_sin;    // float32 kernel: every ray of a wave's 16 x 8 tile is within this angle of the
+    float     cull_cos, cull_sin;    // float32 kernel: every ray of a wave's (8 PPL) x 8 tile is within this angle of the
     int32_t   cull_on;               //   tile's centre ray (bound, padded); cull_on 0: tiles are not contiguous, no culling
     uint32_t* out8;                  // n_frames * width * scan_height
     float*    out32f;                // nullable, n_frames * width * scan_height * 4

@@ -34,6 +34,17 @@ __device__ __forceinline__ void load_f8(ConstF4 rec, f4& lo, f4& hi)
 }
 struct P32Q { f4 g0, g1, g2; };
 __device__ __forceinline__ P32Q load_p32(ConstF4 rec) { P32Q q; load_f8(rec, q.g0, q.g1); q.g2 = rec[2]; return q; }
+// the whole 64-byte record by one s_load_dwordx16 (the record table is 64-byte aligned)
+typedef float f16v __attribute__((ext_vector_type(16)));
+struct P32W { f4 g0, g1, g2, g3; };
+__device__ __forceinline__ P32W load_p32w(ConstF4 rec)
+{
+    const f16v v = *reinterpret_cast<const volatile f16v PTR_CONST*>(rec);
+    P32W q;
+    q.g0 = f4{v[0], v[1], v[2], v[3]};   q.g1 = f4{v[4], v[5], v[6], v[7]};
+    q.g2 = f4{v[8], v[9], v[10], v[11]}; q.g3 = f4{v[12], v[13], v[14], v[15]};
+    return q;
+}
 struct P32G { f4 g0, g1; };
 // the 8 leading floats (shadow test) + the (light, element) pre-filter record
 struct P32H { f4 g0, g1, pa; };
@@ -57,6 +68,8 @@ __device__ __forceinline__ void arrive(const P32Q& q)
 { asm volatile("" ::PTR_F4_IN(q.g0), PTR_F4_IN(q.g1), PTR_F4_IN(q.g2)); }
 __device__ __forceinline__ void arrive_after(const P32Q& q, float dep)
 { asm volatile("" ::PTR_F4_IN(q.g0), PTR_F4_IN(q.g1), PTR_F4_IN(q.g2), "v"(dep)); }
+__device__ __forceinline__ void arrive(const P32W& q)
+{ asm volatile("" ::PTR_F4_IN(q.g0), PTR_F4_IN(q.g1), PTR_F4_IN(q.g2), PTR_F4_IN(q.g3)); }
 __device__ __forceinline__ void arrive(const P32G& q)
 { asm volatile("" ::PTR_F4_IN(q.g0), PTR_F4_IN(q.g1)); }
 __device__ __forceinline__ void arrive(const f4& q)

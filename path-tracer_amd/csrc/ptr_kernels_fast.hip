@@ -7,7 +7,7 @@
 //     no LDS, no bank conflicts.  Each record is requested one sphere ahead of its use;
 //   * the geometry is camera-relative and the per-sphere terms |l|^2 - r^2 etc. are computed
 //     once in float64 on the host, so the primary test is 3 FMAs + 1 compare;
-//   * a wave's pixels are one 16 x 8 tile of the image: lane i first tests sphere i against the cone of
+//   * a wave's pixels are one (8 PPL) x 8 tile of the image: lane i first tests sphere i against the cone of
 //     the tile's rays, and the primary loop visits only the spheres some ray of the tile can reach; the
 //     shadow loop is culled per wave the same way (cone of the wave's shadow rays against the
 //     light -> occluder cones of the host's table);
@@ -36,8 +36,6 @@ struct Pixel {
     F3    d;                    // camera ray direction
     float tnear, t2, etmax;     // nearest / second nearest distance, largest distance error seen
     int   idx;                  // nearest element, -1 = none
-    F3    wl;                   // the nearest element's record so far (copied from the SGPRs when it takes the lead:
-    float wcc, wr2, wlnorm, web; //   no per-lane gather, and no gather latency, after the loop)
 };
 
 // state of a hit pixel during shading
@@ -55,8 +53,19 @@ struct Shade {
     unsigned long long open_m, maybe_m, blocked_m;
 };
 
+// the nearest element of the first lane, in the first pixel slot, that still waits in `rem` (wave-uniform; some lane waits)
+template <int PPL>
+__device__ __forceinline__ int first_waiting(const unsigned long long (&rem)[PPL], const Pixel (&px)[PPL])
+{
+    // (scalar branches: a select between lane masks would turn them into per-lane values)
+#pragma unroll
+    for (int p = 0; p < PPL - 1; p++)
+        if (rem[p] != 0ull) return __builtin_amdgcn_readlane(px[p].idx, (int)__builtin_ctzll(rem[p]));
+    return __builtin_amdgcn_readlane(px[PPL - 1].idx, (int)__builtin_ctzll(rem[PPL - 1]));
+}
+
 template <bool HYBRID, bool DBG, int PPL, bool GENERAL>
-__global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_per_eu(7))) render_fast_kernel(RenderArgs a)
+__global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_per_eu(PTR_FAST_WAVES))) render_fast_kernel(RenderArgs a)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int frame = blockIdx.z;
@@ -69,7 +78,6 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
     const ConstF4 rec0 = (ConstF4)(uintptr_t)(block + a.off_p32);          // uniform reads, 4 f4 per sphere
     const ConstF4 pairs0 = (ConstF4)(uintptr_t)(block + a.off_pairs);      // [light][pair_stride(n)] pre-filter records
     const SphereP32* gp32 = reinterpret_cast<const SphereP32*>(block + a.off_p32);   // per-lane gathers
-    const SphereM32* gm32 = reinterpret_cast<const SphereM32*>(block + a.off_m32);
     const int n = a.n;
 
     // lane i's view of sphere record i for the culling step below, requested first: the latency passes during set-up
@@ -137,7 +145,7 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
 
     stamp(1);
     // ---- which spheres can a ray of this wave reach at all? ---------------------------------------
-    // The wave's pixels form a 16 x 8 block of the image, so its rays lie in a narrow cone around the
+    // The wave's pixels form a (8 PPL) x 8 block of the image, so its rays lie in a narrow cone around the
     // block's centre ray dc (half-angle bound from the host, cull_sin / cull_cos).  A ray of the cone can
     // only hit sphere i if the angle between dc and l_i is at most that half-angle plus the sphere's own
     // angular radius asin(r / |l|):  l.dc >= cos(T) sqrt(cc) - sin(T) r.  Lane i evaluates this for sphere
@@ -197,23 +205,13 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
             const float t = hit ? fmaf(q.g2.x, disc * s, b) : 3.0e38f;      // t0, or t1 when t0 < 0 (RayTracer.js:32-34)
             r.etmax = fmax_raw(r.etmax, hit ? fmaf(0.5f * q.g1.x, s, q.g2.w) : 0.0f);     // |dt| <= md / (2 thc) + eb
             r.t2 = __builtin_amdgcn_fmed3f(r.tnear, r.t2, t);   // second smallest so far
-            if (t < r.tnear) {                         // strict: the first of equals stays (RayTracer.js:36)
-                r.idx = i;
-                r.wl = F3{q.g0.x, q.g0.y, q.g0.z}; r.wcc = q.g0.w; r.wr2 = q.g1.z; r.wlnorm = q.g1.w; r.web = q.g2.w;
-            }
+            r.idx = t < r.tnear ? i : r.idx;           // strict: the first of equals stays (RayTracer.js:36)
             r.tnear = fmin_raw(r.tnear, t);
         }
     };
     {
         // Two record buffers in SGPRs: the next candidate's record is requested before the current one is
         // used.  Record n exists (zero padding), so "no next candidate" needs no special case.
-        // the winner's record has no initial value: every use of it is masked by idx >= 0 (any bit pattern will do,
-        // and seven moves per pixel slot are saved)
-#pragma unroll
-        for (int p = 0; p < PPL; p++) {
-            Pixel& q = px[p];
-            any_value(q.wl.x); any_value(q.wl.y); any_value(q.wl.z); any_value(q.wcc); any_value(q.wr2); any_value(q.wlnorm); any_value(q.web);
-        }
         if (cand != 0u) {
             unsigned todo = cand;
             const unsigned stop = 1u << n;             // record n: the zero padding
@@ -284,56 +282,92 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
         const float4* lane_pairs = reinterpret_cast<const float4*>(block + a.off_pairs) + li;
         float4 pq = load_f4(lane_pairs);
         const F3 cj = load_f3(&gp32[li].lx);
+        // ---- the winners, recomputed accurately: one trip per DISTINCT nearest element of the wave -----------------
+        // Nearly every wave that shades sees one element in all its pixels (95 % on the example scene): its record is
+        // fetched by ONE scalar load and used straight from SGPRs by all lanes; a wave on a silhouette takes a second
+        // trip for the lanes of the other element.  No per-lane copy of the record is kept anywhere.
+        // disc' = r^2 - |l x d|^2 has no cancellation between |l|^2 and b^2, and the nearest
+        // root is taken in its cancellation-free form t = cc / (b + thc).
 #pragma unroll
-        for (int p = 0; p < PPL; p++) {
-            Pixel& r = px[p];
+        for (int p = 0; p < PPL; p++) {               // (written under a lane mask below: any value will do until then)
             Shade& s = sh[p];
-            const int idx = s.valid ? r.idx : 0;
-            // ---- winner, recomputed accurately ---------------------------------------------------
-            // disc' = r^2 - |l x d|^2 has no cancellation between |l|^2 and b^2, and the nearest
-            // root is taken in its cancellation-free form t = cc / (b + thc).
-            const F3 lw = r.wl;
-            const float cc_w = r.wcc, r2_w = r.wr2, lnorm_w = r.wlnorm, eb_w = r.web;
-            const float inv_r = rsq(fmax_raw(r2_w, 1e-30f));
-            // half the error bound of disc' = r^2 - |l x d|^2: 10 eps r |l| + 2 eps r^2 (r from r^2: 2 more eps)
-            const float hed_w = (10.5f * EPS) * (r2_w * inv_r) * lnorm_w + (2.5f * EPS) * r2_w;
-            const F3 d = r.d;
-            const float b_w = dot3(lw, d);
-            const F3 cr3{fmaf(lw.y, d.z, -lw.z * d.y), fmaf(lw.z, d.x, -lw.x * d.z), fmaf(lw.x, d.y, -lw.y * d.x)};
-            const float disc_w = fmaxf(r2_w - dot3(cr3, cr3), 1e-30f);
-            const float s_w = rsq(disc_w);
-            const float thc_w = disc_w * s_w;
-            const float et_w = fmaf(hed_w, s_w, eb_w);     // |error of (b + thc)|
-            const float bt = b_w + thc_w;
-            const float rbt = rcp(bt);
-            const bool outside = cc_w > 0.0f;
-            s.self = outside ? idx : -1;
-            s.t = outside ? cc_w * rbt : bt;
-            s.eP = outside ? s.t * fmaf(et_w, rbt, 4.0f * EPS) : fmaf(2.0f * EPS, s.t, et_w);   // |error of P|
-
-            // ---- hit frame (RayTracer.js:48-58), camera-relative -------------------------------
-            s.P = F3{d.x * s.t, d.y * s.t, d.z * s.t};
-            // P - C (Sphere.js:47-51), normalised by 1 / r: the true hit point lies ON the sphere, so this differs from
-            // the true normal by (error of P) / r, which eN below already counts
-            F3 N{s.P.x - lw.x, s.P.y - lw.y, s.P.z - lw.z};
-            const float sg = outside ? inv_r : -inv_r; // inside: d.N > 0 -> revert (RayTracer.js:54-58)
-            s.N = F3{N.x * sg, N.y * sg, N.z * sg};
-            s.eN = fmaf(s.eP + EPS * (lnorm_w + s.t), inv_r, 15.0f * EPS);  // |error of N| (1 / r itself: 2 eps), + 10 eps for the
-                                                                            //   rounding of N.L and of the sums over the lights
+            any_value(s.P.x); any_value(s.P.y); any_value(s.P.z); any_value(s.N.x); any_value(s.N.y); any_value(s.N.z);
+            any_value(s.t); any_value(s.eP); any_value(s.eN);
+            s.self = -1;
             s.ar = 0.0f; s.ag = 0.0f; s.ab = 0.0f; s.werr = 0.0f;
+        }
+        {
+            unsigned long long rem[PPL];
+#pragma unroll
+            for (int p = 0; p < PPL; p++) rem[p] = sh[p].valid_m;
+            for (;;) {
+                // the element of the first lane that still waits (wave-uniform)
+                int w = first_waiting(rem, px);
+                w &= 15;                                   // (tells the compiler that the index is small)
+                const P32W W = load_p32w(rec0 + 4u * (unsigned)w);
+                unsigned long long m[PPL];
+#pragma unroll
+                for (int p = 0; p < PPL; p++) { m[p] = ballot(px[p].idx == w); rem[p] &= ~m[p]; }
+                arrive(W);
+                const float cc_w = W.g0.w, r2_w = W.g1.z, lnorm_w = W.g1.w, eb_w = W.g2.w, inv_r = W.g3.x, hed_w = W.g3.y;
+                const bool outside = cc_w > 0.0f;          // wave-uniform: a scalar branch, not selects
+#pragma unroll
+                for (int p = 0; p < PPL; p++) {
+                    if (m[p] == 0ull) continue;            // wave-uniform
+                    if (lane_of(m[p])) {
+                        Shade& s = sh[p];
+                        const F3 d = px[p].d;
+                        const float b_w = fmaf(W.g0.z, d.z, fmaf(W.g0.y, d.y, W.g0.x * d.x));
+                        const F3 cr3{fmaf(W.g0.y, d.z, -(W.g0.z * d.y)), fmaf(W.g0.z, d.x, -(W.g0.x * d.z)), fmaf(W.g0.x, d.y, -(W.g0.y * d.x))};
+                        const float disc_w = fmaxf(r2_w - dot3(cr3, cr3), 1e-30f);
+                        const float s_w = rsq(disc_w);
+                        const float thc_w = disc_w * s_w;
+                        const float et_w = fmaf(hed_w, s_w, eb_w);     // |error of (b + thc)|
+                        const float bt = b_w + thc_w;
+                        const float rbt = rcp(bt);
+                        float sg;
+                        if (outside) {
+                            s.self = w;
+                            s.t = cc_w * rbt;
+                            s.eP = s.t * fmaf(et_w, rbt, 4.0f * EPS);  // |error of P|
+                            sg = inv_r;
+                        } else {
+                            s.t = bt;
+                            s.eP = fmaf(2.0f * EPS, s.t, et_w);
+                            sg = -inv_r;                               // inside: d.N > 0 -> revert (RayTracer.js:54-58)
+                        }
+                        // ---- hit frame (RayTracer.js:48-58), camera-relative -------------------------------
+                        s.P = F3{d.x * s.t, d.y * s.t, d.z * s.t};
+                        // P - C (Sphere.js:47-51), normalised by 1 / r: the true hit point lies ON the sphere, so this differs
+                        // from the true normal by (error of P) / r, which eN below already counts
+                        s.N = F3{(s.P.x - W.g0.x) * sg, (s.P.y - W.g0.y) * sg, (s.P.z - W.g0.z) * sg};
+                        s.eN = fmaf(s.eP + EPS * (lnorm_w + s.t), inv_r, 15.0f * EPS);  // |error of N| (1 / r itself: 2 eps), + 10 eps for
+                                                                                        //   the rounding of N.L and of the sums over the lights
+                    }
+                }
+                unsigned long long left = 0ull;
+#pragma unroll
+                for (int p = 0; p < PPL; p++) left |= rem[p];
+                if (left == 0ull) break;
+            }
         }
         // (after the arithmetic above: this is the first use of a word requested at the top)
 #pragma unroll
-        for (int p = 0; p < PPL; p++) sh[p].self = (sh[p].valid & self_ok) ? sh[p].self : -1;
+        for (int p = 0; p < PPL; p++) sh[p].self = self_ok ? sh[p].self : -1;      // (lanes without a hit hold -1 already)
         // The wave's shadow-ray origins lie in a ball: centre = the first shaded lane's hit point, radius = the largest
         // distance of a shaded lane's P from it, plus the error of P and the 1e-4 bias (used by cone_prefilter).
         float pcx, pcy, pcz, prad;
         {
-            const unsigned long long v0 = sh[0].valid_m;
-            const bool first = v0 != 0ull || PPL == 1;
-            const Shade& sa = sh[first ? 0 : PPL - 1];
-            const int src = (int)__builtin_ctzll(first ? v0 : sa.valid_m);
-            pcx = readlane_f(sa.P.x, src); pcy = readlane_f(sa.P.y, src); pcz = readlane_f(sa.P.z, src);
+            int ps = PPL - 1;                                  // the first slot with a shaded lane (scalar branches)
+#pragma unroll
+            for (int p = PPL - 2; p >= 0; p--) ps = sh[p].valid_m != 0ull ? p : ps;
+            pcx = pcy = pcz = 0.0f;
+#pragma unroll
+            for (int p = 0; p < PPL; p++)
+                if (ps == p) {
+                    const int src = (int)__builtin_ctzll(sh[p].valid_m);
+                    pcx = readlane_f(sh[p].P.x, src); pcy = readlane_f(sh[p].P.y, src); pcz = readlane_f(sh[p].P.z, src);
+                }
             float dev = 0.0f;
 #pragma unroll
             for (int p = 0; p < PPL; p++) {
@@ -497,34 +531,58 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
         stamp(5);
         // the background (RayTracer.js:43-46, bit-exact by construction) is read only here: four SGPRs fewer to carry
         const uint32_t bg_packed = hdr->bg_packed;
-        // the winners' materials, gathered only now (all requests first): surfaceColor * (sum over lights) + emission
-        // (RayTracer.js:85-93)
-        SphereM32 mws[PPL];
-#pragma unroll
-        for (int p = 0; p < PPL; p++) mws[p] = gm32[sh[p].valid ? (px[p].idx & 0xFF) : 0];
+        // surfaceColor * (sum over lights) + emission (RayTracer.js:85-93), clamp, round, pack (RayTracer.js:179-192) with a
+        // rounding bound: again one trip per distinct nearest element, its material straight from SGPRs
+        float rdoubt[PPL];                         // distance of the nearest rounding boundary minus its error band
 #pragma unroll
         for (int p = 0; p < PPL; p++) {
-            Shade& s = sh[p];
-            const SphereM32 mw = mws[p];
-            const float hr = fmaf(mw.sr, s.ar, mw.er), hg = fmaf(mw.sg, s.ag, mw.eg), hb = fmaf(mw.sb, s.ab, mw.eb);
-            // ---- clamp, round, pack (RayTracer.js:179-192) with a rounding bound ----------------
-            // |error of N.L| <= eN + eL (+ rounding of the dot and of the sums, 8 eps)
-            const float band = 255.0f * fmaf(mw.scmax, s.werr, 4.0f * EPS * mw.emax) + 2e-5f;
-            // Math.round(v) = floor(v + 0.5); v + 0.5 is exact in float32 for 0.5 <= v < 256, and below 0.5 it can only
-            // round across 1.0 within the band that is re-traced anyway
-            const float vr = fmin_raw(hr, 1.0f) * 255.0f, vg = fmin_raw(hg, 1.0f) * 255.0f, vb = fmin_raw(hb, 1.0f) * 255.0f;
-            const float qr = __builtin_amdgcn_fractf(vr) - 0.5f, qg = __builtin_amdgcn_fractf(vg) - 0.5f,
-                        qb = __builtin_amdgcn_fractf(vb) - 0.5f;
-            const float nearest = fminf(fminf(fabsf(qr), fabsf(qg)), fabsf(qb));
-            // HYBRID: a pixel in doubt for any OTHER reason is re-traced from scratch (bit 9 of its idx register: one lane
-            // mask, not two, stays in SGPRs); one that is only here for its rounding gets the shading-only re-do
+            packed[p] = bg_packed; rdoubt[p] = 1.0f; shaded_m[p] = sh[p].valid_m;
+            any_value(cr[p]); any_value(cg[p]); any_value(cb[p]);
+            // HYBRID: a pixel in doubt for any reason OTHER than its rounding is re-traced from scratch (bit 9 of its idx
+            // register: one lane mask, not two, stays in SGPRs); one that is only here for its rounding gets the shading-only re-do
             if constexpr (HYBRID) px[p].idx |= unsure[p].any() ? 0x200 : 0;
-            unsure[p].add_mask(ballot(nearest <= band) & s.valid_m, WHY_ROUND);
-            const uint32_t r8 = (uint32_t)(vr + 0.5f), g8 = (uint32_t)(vg + 0.5f), b8 = (uint32_t)(vb + 0.5f);
-            // (a select, spelled out: the compiler otherwise switches the unshaded lanes off around the conversion above)
-            packed[p] = select_u32(s.valid_m, (255u << 24) | (b8 << 16) | (g8 << 8) | r8, bg_packed);
-            cr[p] = hr; cg[p] = hg; cb[p] = hb; shaded_m[p] = s.valid_m;
         }
+        const ConstF4 mat0 = (ConstF4)(uintptr_t)(block + a.off_m32);
+        {
+            unsigned long long rem[PPL];
+#pragma unroll
+            for (int p = 0; p < PPL; p++) rem[p] = sh[p].valid_m;
+            for (;;) {
+                int w = first_waiting(rem, px);
+                w &= 15;
+                f4 mlo, mhi;                               // sr sg sb scmax | er eg eb emax
+                load_f8(mat0 + 2u * (unsigned)w, mlo, mhi);
+                unsigned long long m[PPL];
+#pragma unroll
+                for (int p = 0; p < PPL; p++) { m[p] = ballot((px[p].idx & 0xFF) == w); rem[p] &= ~m[p]; }
+                arrive(mlo); arrive(mhi);
+#pragma unroll
+                for (int p = 0; p < PPL; p++) {
+                    if (m[p] == 0ull) continue;            // wave-uniform
+                    if (lane_of(m[p])) {
+                        const Shade& s = sh[p];
+                        const float hr = fmaf(mlo.x, s.ar, mhi.x), hg = fmaf(mlo.y, s.ag, mhi.y), hb = fmaf(mlo.z, s.ab, mhi.z);
+                        // |error of N.L| <= eN + eL (+ rounding of the dot and of the sums, 8 eps)
+                        const float band = 255.0f * fmaf(mlo.w, s.werr, 4.0f * EPS * mhi.w) + 2e-5f;
+                        // Math.round(v) = floor(v + 0.5); v + 0.5 is exact in float32 for 0.5 <= v < 256, and below 0.5 it can only
+                        // round across 1.0 within the band that is re-traced anyway
+                        const float vr = fmin_raw(hr, 1.0f) * 255.0f, vg = fmin_raw(hg, 1.0f) * 255.0f, vb = fmin_raw(hb, 1.0f) * 255.0f;
+                        const float qr = __builtin_amdgcn_fractf(vr) - 0.5f, qg = __builtin_amdgcn_fractf(vg) - 0.5f,
+                                    qb = __builtin_amdgcn_fractf(vb) - 0.5f;
+                        rdoubt[p] = fminf(fminf(fabsf(qr), fabsf(qg)), fabsf(qb)) - band;
+                        const uint32_t r8 = (uint32_t)(vr + 0.5f), g8 = (uint32_t)(vg + 0.5f), b8 = (uint32_t)(vb + 0.5f);
+                        packed[p] = (255u << 24) | (b8 << 16) | (g8 << 8) | r8;
+                        cr[p] = hr; cg[p] = hg; cb[p] = hb;
+                    }
+                }
+                unsigned long long left = 0ull;
+#pragma unroll
+                for (int p = 0; p < PPL; p++) left |= rem[p];
+                if (left == 0ull) break;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < PPL; p++) unsure[p].add_mask(ballot(rdoubt[p] <= 0.0f), WHY_ROUND);   // (lanes without a hit hold 1)
     } else {
 #pragma unroll
         for (int p = 0; p < PPL; p++) { cr[p] = 0.0f; cg[p] = 0.0f; cb[p] = 0.0f; shaded_m[p] = 0ull; packed[p] = hdr->bg_packed; }

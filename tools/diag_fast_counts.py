@@ -16,9 +16,14 @@ r.set_elements(sc["elements"]); r.set_background(sc["background"])
 DBG = ptr_amd.MODE_F32_ONLY | 0x8000
 
 
+import re
+PPL = int(re.search(r"define PTR_FAST_PPL (\d+)", open(os.path.join(ROOT, "path-tracer_amd/csrc/ptr_device.h")).read()).group(1))
+TW = 8 * PPL
+
+
 def tiles(img, rows):
-    """one row of values per wave tile (16 wide x 8 tall, the two pixel slots side by side): the tile's first pixel row"""
-    return img[: rows // 8 * 8].reshape(rows // 8, 8, w // 16, 16)[:, 0]
+    """one row of values per wave tile (8 * PPL wide x 8 tall, the pixel slots side by side): the tile's first pixel row"""
+    return img[: rows // 8 * 8].reshape(rows // 8, 8, w // TW, TW)[:, 0]
 
 
 why = r.render(w, h, flags=DBG).reshape(h, w)
