@@ -530,7 +530,7 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
     hipError_t e = many ? launch_render_many(a, n_frames, true, s) : launch_render_fast(a, n_frames, true, s);
     if (e == hipSuccess && timing) e = hipEventRecord(c->ev[1], s);
     if (e == hipSuccess) {
-        e = launch_retrace_exact(a, many ? 8 : 1, s);
+        e = many ? launch_retrace_exact(a, 8, 8, s) : launch_retrace_exact(a, 1, 4, s);
         if (e == hipSuccess && timing) { e = hipEventRecord(c->ev[2], s); c->timed_kernels = 2; }
     }
     if (e != hipSuccess) {

@@ -7,7 +7,7 @@ namespace ptr {
 
 // float64, op-for-op the reference (ptr_kernels_exact.hip)
 hipError_t launch_render_exact(const RenderArgs& a, int n_frames, bool stats, hipStream_t s);
-hipError_t launch_retrace_exact(const RenderArgs& a, int split, hipStream_t s);   // split: workgroups per sub-queue
+hipError_t launch_retrace_exact(const RenderArgs& a, int parts1, int parts0, hipStream_t s);   // workgroups per sub-queue: shading-only entries / full re-traces
 hipError_t launch_trace_batch_exact(const TraceArgs& a, hipStream_t s);
 
 // float32 with uncertainty filter (ptr_kernels_fast.hip); hybrid = queue unsure pixels

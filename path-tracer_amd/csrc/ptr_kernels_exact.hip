@@ -285,22 +285,28 @@ __device__ V3 trace_exact_wide(const FrameView& fv, V3 o, V3 d)
 // synchronises between the two kernels.  kind 0 (blockIdx.y == 0): re-trace the pixel from scratch;
 // kind 1: the nearest element is certain and so are some of the shadow verdicts (qinfo), only the
 // shading is redone in float64 (entries stored from the back of the sub-queue).
+template <int KIND>        // one kernel per kind: the shading-only one needs far fewer registers than the full re-trace
 __global__ void __launch_bounds__(PTR_BLOCK) retrace_exact_kernel(RenderArgs a)
 {
-    // The grid always has PTR_MAX_QUEUES x 2 workgroups: every counter of the OTHER set is zeroed for the
+    // The grid always has PTR_MAX_QUEUES x (parts1 + parts0) workgroups: every counter of the OTHER set is zeroed for the
     // next call (which may use more sub-queues than this one); workgroups past n_queues do only that.
-    const uint32_t sub = blockIdx.x, kind = blockIdx.y;
-    if (threadIdx.x == 0 && blockIdx.z == 0) a.counter_next[sub * PTR_COUNTER_STRIDE + kind] = 0u;
+    // blockIdx.y < parts1: part blockIdx.y of the sub-queue's shading-only entries (kind 1); the others: a part of its
+    // full re-traces (kind 0) - those take several times longer per entry, so they are spread over more workgroups.
+    const uint32_t sub = blockIdx.x;
+    constexpr uint32_t kind = (uint32_t)KIND;
+    const uint32_t part = blockIdx.y;
+    const uint32_t nparts = gridDim.y;
+    if (threadIdx.x == 0 && part == 0) a.counter_next[sub * PTR_COUNTER_STRIDE + kind] = 0u;
     if (sub >= a.n_queues) return;
     const uint32_t fill = a.counter[sub * PTR_COUNTER_STRIDE + kind];
     const uint32_t count = fill < a.queue_capacity ? fill : a.queue_capacity;
     const uint32_t* queue = a.queue + (uint64_t)sub * a.queue_capacity;
     const uint32_t* qinfo = a.qinfo + 2 * (uint64_t)sub * a.queue_capacity;
     const uint64_t frame_px = (uint64_t)a.width * (uint64_t)a.scan_height;
-    if (kind == 0 && a.n >= PTR_WIDE_RETRACE_MIN) {
+    if (KIND == 0 && a.n >= PTR_WIDE_RETRACE_MIN) {
         // many spheres: one wave per queued pixel (trace_exact_wide), waves of all the sub-queue's workgroups take turns
-        const uint32_t waves = (blockDim.x >> 6) * gridDim.z;
-        for (uint32_t q = blockIdx.z * (blockDim.x >> 6) + (threadIdx.x >> 6); q < count; q += waves) {
+        const uint32_t waves = (blockDim.x >> 6) * nparts;
+        for (uint32_t q = part * (blockDim.x >> 6) + (threadIdx.x >> 6); q < count; q += waves) {
             const uint64_t gid = queue[q];
             if (gid >= frame_px * (uint64_t)a.n_frames) continue;
             const int frame = (int)(gid / frame_px);
@@ -318,25 +324,34 @@ __global__ void __launch_bounds__(PTR_BLOCK) retrace_exact_kernel(RenderArgs a)
                 }
             }
         }
-        if (threadIdx.x == 0 && blockIdx.z == 0 && a.stats) atomicAdd(&a.stats[ST_RETRACED], (unsigned long long)count);
+        if (threadIdx.x == 0 && part == 0 && a.stats) atomicAdd(&a.stats[ST_RETRACED], (unsigned long long)count);
         return;
     }
-    // gridDim.z workgroups share a sub-queue (many spheres: an entry is long, spread them wide)
-    for (uint32_t q = blockIdx.z * blockDim.x + threadIdx.x; q < count; q += blockDim.x * gridDim.z) {
+    // nparts workgroups share a sub-queue's entries of this kind
+    // (a call holds fewer than 2^32 pixels, checked by the host: ids and their divisions are 32-bit; the block's tables are
+    // found from the layout the host passes, not from the header: one dependent load less on every entry's critical path)
+    const uint32_t frame_px32 = (uint32_t)frame_px, total_px = frame_px32 * (uint32_t)a.n_frames;
+    for (uint32_t q = part * blockDim.x + threadIdx.x; q < count; q += blockDim.x * nparts) {
         const uint32_t slot = kind ? a.queue_capacity - 1u - q : q;
-        const uint64_t gid = queue[slot];
-        if (gid >= frame_px * (uint64_t)a.n_frames) continue;      // never trust a queue word blindly
-        const int frame = (int)(gid / frame_px);
-        const uint32_t pix = (uint32_t)(gid - (uint64_t)frame * frame_px);
+        const uint32_t gid = queue[slot];
+        if (gid >= total_px) continue;                             // never trust a queue word blindly
+        const uint32_t frame = gid / frame_px32;
+        const uint32_t pix = gid - frame * frame_px32;
         const int row = (int)(pix / (uint32_t)a.width), x = (int)(pix - (uint32_t)row * a.width);
-        const unsigned char* block = a.scenes + (uint64_t)(a.first_frame + frame) * a.frame_stride;
-        const FrameView fv = frame_view(block);
+        const unsigned char* block = a.scenes + (uint64_t)(a.first_frame + (int)frame) * a.frame_stride;
+        FrameView fv;
+        fv.h = reinterpret_cast<const FrameHeader*>(block);
+        fv.g64 = reinterpret_cast<const SphereG64*>(block + sizeof(FrameHeader));
+        fv.m64 = reinterpret_cast<const SphereM64*>(block + sizeof(FrameHeader) + sizeof(SphereG64) * (size_t)a.n);
+        fv.p32 = reinterpret_cast<const SphereP32*>(block + a.off_p32);
+        fv.m32 = reinterpret_cast<const SphereM32*>(block + a.off_m32);
+        fv.lights = reinterpret_cast<const int32_t*>(block + a.off_lights);
         V3 o{a.cam.org[0], a.cam.org[1], a.cam.org[2]};
         V3 d = primary_dir_exact(a.cam, x, global_y(a, row));
         V3 c;
-        if (kind) {
+        if constexpr (KIND == 1) {
             const uint32_t element = qinfo[2 * slot], codes = qinfo[2 * slot + 1];
-            if (element >= (uint32_t)fv.h->n) continue;
+            if (element >= (uint32_t)a.n) continue;
             c = reshade_exact(fv, o, d, (int)element, codes);
         } else {
             c = trace_exact<false>(fv, o, d, nullptr, nullptr);
@@ -348,7 +363,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) retrace_exact_kernel(RenderArgs a)
             p[0] = (float)c.x; p[1] = (float)c.y; p[2] = (float)c.z; p[3] = 1.0f;
         }
     }
-    if (threadIdx.x == 0 && blockIdx.z == 0 && a.stats) atomicAdd(&a.stats[kind ? ST_RESHADED : ST_RETRACED], (unsigned long long)count);
+    if (threadIdx.x == 0 && part == 0 && a.stats) atomicAdd(&a.stats[kind ? ST_RESHADED : ST_RETRACED], (unsigned long long)count);
 }
 
 __global__ void __launch_bounds__(PTR_BLOCK) trace_batch_exact_kernel(TraceArgs a)
@@ -390,9 +405,11 @@ hipError_t launch_render_exact(const RenderArgs& a, int n_frames, bool stats, hi
     return hipGetLastError();
 }
 
-hipError_t launch_retrace_exact(const RenderArgs& a, int split, hipStream_t s)
+hipError_t launch_retrace_exact(const RenderArgs& a0, int parts1, int parts0, hipStream_t s)
 {
-    hipLaunchKernelGGL(retrace_exact_kernel, dim3(PTR_MAX_QUEUES, 2, split), dim3(PTR_BLOCK), 0, s, a);
+    const RenderArgs& a = a0;
+    hipLaunchKernelGGL(retrace_exact_kernel<0>, dim3(PTR_MAX_QUEUES, parts0, 1), dim3(PTR_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(retrace_exact_kernel<1>, dim3(PTR_MAX_QUEUES, parts1, 1), dim3(PTR_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 
