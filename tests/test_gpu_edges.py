@@ -273,3 +273,34 @@ def test_wide_and_skewed_cameras_render_the_reference_bytes(scenes):
             assert np.array_equal(exact, want), c
     finally:
         r.close()
+
+
+def test_long_odd_sequence_three_calls_in_a_row(scenes):
+    """37 different frames per call, three calls back to back (the queue's counter sets alternate from call to call), the
+    last one with the float32 framebuffer as well: every frame against the oracle"""
+    torch = pytest.importorskip("torch")
+    sc = scenes["example1"]
+    base = ptr_amd.scene_to_soa(sc["elements"])
+    nf, w, h = 37, 200, 96
+    frames = []
+    for f in range(nf):
+        s = base.copy(); s[0, 1:5] += 0.11 * f; s[1, 2] = -1.0 + 0.07 * f
+        frames.append(s)
+    r = ptr_amd.Renderer(0)
+    try:
+        r.set_scene(np.stack(frames)); r.set_background(sc["background"])
+        st = torch.cuda.Stream()
+        out = torch.empty((nf, h, w), dtype=torch.int32, device="cuda")
+        f32 = torch.empty((nf, h, w, 4), dtype=torch.float32, device="cuda")
+        want = [orc.render(frames[f], sc["background"], w, h, flags=0).reshape(h, w) for f in range(nf)]
+        for rep in range(3):
+            out.fill_(0)
+            r.render_device(r.params(w, h, flags=0), 0, nf, out.data_ptr(), f32.data_ptr() if rep == 2 else None, stream=st.cuda_stream)
+            torch.cuda.synchronize()
+            got = out.cpu().numpy().view(np.uint32)
+            for f in range(nf):
+                assert np.array_equal(got[f], want[f]), (rep, f)
+        assert r.stats()["retraced"] + r.stats()["reshaded"] > 0
+        assert float(f32[nf - 1, 0, 0, 3]) == 1.0
+    finally:
+        r.close()
