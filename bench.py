@@ -35,10 +35,11 @@ STRIP = 8
 PEAK_FP32_VALU_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
 PEAK_HBM_GBPS = 8000.0
 # HBM traffic of the float32 kernel per pixel, from the PMC passes of this very command kept under profiles/
-# (r01_summary.md: WRITE_SIZE 2 238 650 KB and FETCH_SIZE 3 499.8 KB per launch of 256 x 1920 x 1080 pixels; gfx950
+# (r02_summary.md: WRITE_SIZE 2 615 750 KB and FETCH_SIZE 9 856.6 KB per launch of 256 x 1920 x 1080 pixels; gfx950
 # correction of the guide applied: FETCH_SIZE counts 64 B per 128-B request -> x 2).  Counters cannot be read from
-# inside this process, so the per-launch figure reported below is this measured rate times the launch's pixels.
-MEASURED_HBM_BYTES_PER_PIXEL = (2238650.0 * 1024 + 2 * 3499.84 * 1024) / (256 * 1920 * 1080)
+# inside this process, so the per-launch figure reported below is this profiled rate times the launch's pixels
+# (reported as "traffic", with "traffic_source" saying so).
+PROFILED_HBM_BYTES_PER_PIXEL = (2615750.0 * 1024 + 2 * 9856.63 * 1024) / (256 * 1920 * 1080)
 
 
 def example1_soa():
@@ -290,15 +291,18 @@ def main():
             "roofline": {"bound": "valu", "kernel": "render_fast_kernel<hybrid>",
                          "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
-                         "traffic": int(MEASURED_HBM_BYTES_PER_PIXEL * WIDTH * local_rows * frames_total),
-                         "traffic_note": "HBM bytes per launch = PMC-measured bytes per pixel (profiles/r01_summary.md, "
-                                         "WRITE_SIZE + 2 x FETCH_SIZE passes of this command) x pixels of this launch; "
-                                         "algorithmic bytes = 4 per pixel",
+                         "frac_step": round(launch_flops / (elapsed / args.steps) / 1e12 / PEAK_FP32_VALU_TFLOPS, 4),
+                         "traffic": int(PROFILED_HBM_BYTES_PER_PIXEL * WIDTH * local_rows * frames_total),
+                         "traffic_source": "not measured in this run: PMC bytes per pixel of the profiled run of this command "
+                                           "(profiles/r02_summary.md, WRITE_SIZE + 2 x FETCH_SIZE passes) x pixels of this "
+                                           "launch; algorithmic bytes = 4 per pixel",
                          "kernel_ms": round(main_ms, 4), "retrace_kernel_ms": round(retrace_ms, 4),
                          "algorithmic_flops_per_launch": int(launch_flops),
                          "hbm_frac": round(launch_bytes / (main_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
                          "note": "FP32 vector-ALU bound (SURVEY.md 8d): no dense contraction, 4 B/pixel of HBM "
-                                 "traffic; achieved = algorithmic FLOPs of the reference's control flow"},
+                                 "traffic; achieved = algorithmic FLOPs of the reference's control flow / the float32 kernel's "
+                                 "own time; frac_step = the same FLOPs / the whole timed step (float32 kernel + float64 "
+                                 "re-trace + gaps), i.e. what the path delivers with the reference's bytes"},
         }
         if render_only is not None:
             out["phases"] = {
