@@ -33,6 +33,35 @@ CASES = [   # scene, width, height, max_depth, spp, seed, keep the frame (else h
 ]
 
 
+# BASELINE.json configs[2] and [3] on the synthetic scene of path-tracer_amd/py/ptr_amd/synthetic.py:
+# hashes only (minutes of CPU each); C4 = the rows of ONE part of the 8-way cyclic 8-row strip partition of a 4K frame
+CONFIG_SEED = 0x5EED1234
+CONFIG_CASES = [   # key, width, height, max_depth, spp, (n_parts, part, strip_height) or None
+    ("config2@1920x1080_d5_s64", 1920, 1080, 5, 64, None),
+    ("config3_part3of8@3840x2160_d5_s256", 3840, 2160, 5, 256, (8, 3, 8)),
+]
+
+
+def config_cases(index):
+    sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd", "py"))
+    from ptr_amd import synthetic as syn          # scene data only (no GPU code is touched)
+    soa = syn.config3_scene()
+    for key, w, h, depth, spp, strips in CONFIG_CASES:
+        if strips is None:
+            out = orc.render_ext(soa, syn.BACKGROUND, w, h, max_depth=depth, spp=spp, seed=CONFIG_SEED, threads=8)
+        else:
+            n_parts, part, sh = strips
+            rows = []
+            for k in range(part, (h + sh - 1) // sh, n_parts):
+                rows.append(orc.render_ext(soa, syn.BACKGROUND, w, h, start_y=k * sh, scan_height=min(sh, h - k * sh),
+                                           max_depth=depth, spp=spp, seed=CONFIG_SEED, threads=8))
+            out = np.concatenate(rows)
+        index["cases"][key] = dict(scene="synthetic.config3_scene", width=w, height=h, max_depth=depth, spp=spp, seed=CONFIG_SEED,
+                                   strips=list(strips) if strips else None, pixels=int(out.size),
+                                   sha256=hashlib.sha256(out.tobytes()).hexdigest())
+        print(key, index["cases"][key]["sha256"][:16], flush=True)
+
+
 def main():
     scenes = orc.load_scenes(GOLDEN)
     index = {"note": "outputs of oracle/ptr_oracle.c orc_render_ext (the extension-mode specification); "
@@ -51,6 +80,7 @@ def main():
             entry["file"] = rel
         index["cases"][key] = entry
         print(key, entry["sha256"][:16])
+    config_cases(index)
     with open(os.path.join(GOLDEN, "ext", "index.json"), "w") as f:
         json.dump(index, f, indent=1)
 
