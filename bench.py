@@ -12,9 +12,14 @@ Scene blocks are resident in HBM before the timed region and the frames stay in 
 
 N > 1: every frame is split into cyclic strips of 8 scanlines over the ranks (the reference's
 RenderPlanner band split, RT/src/RenderPlanner.js:75-76, made cyclic for load balance); every
-step ends with the gather of all strips to rank 0 over RCCL (torch.distributed "nccl") and the
-re-interleave there, inside the timed region.  Weak scaling: each rank renders FRAMES * N frames'
-worth of its strips, i.e. per-GPU work is fixed as N grows.
+step's strips are gathered into whole frames on rank 0 over RCCL by the library's own gather
+(ptr_gather_strips_device: grouped ncclSend / ncclRecv straight over each peer's xGMI link, then one
+copy kernel on rank 0), on a communication stream, double-buffered, so that step k's gather runs
+under step k + 1's render; all of it inside the timed region (the last gather included).  The first
+gathered frame is checked against a single-GPU render before anything is timed; if the library's
+gather cannot be used (ranks sharing a GPU in a rehearsal, no RCCL) the bench says so ("gather":
+"torch") and gathers with torch.distributed + the library's copy kernel instead.  Weak scaling:
+each rank renders FRAMES * N frames' worth of its strips, i.e. per-GPU work is fixed as N grows.
 
 Prints ONE JSON line on rank 0.
 """
@@ -116,6 +121,9 @@ def main():
 
     import torch
     import ptr_amd
+    if os.environ.get("PTR_BENCH_HANG_DUMP"):            # rehearsals: where is everybody after that many seconds?
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["PTR_BENCH_HANG_DUMP"]), exit=True)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -167,39 +175,118 @@ def main():
         part = ptr_amd.StripPart(world, rank, STRIP)
         local_rows = part.local_rows(HEIGHT)
     max_rows = ptr_amd.StripPart(world, 0, STRIP).local_rows(HEIGHT) if world > 1 else HEIGHT
-    local = torch.empty((frames_total, max_rows, WIDTH), dtype=torch.int32, device="cuda")
+    n_buf = 2 if world > 1 else 1                # double-buffered: a gather reads one while the next step renders into the other
+    locals_ = [torch.empty((frames_total, max_rows, WIDTH), dtype=torch.int32, device="cuda") for _ in range(n_buf)]
+    local = locals_[0]
     p = rdr.params(WIDTH, HEIGHT, 0, local_rows, flags=0)
-    gathered = full = row_index = None
+    full = None
     if world > 1 and rank == 0:
-        gathered = [torch.empty_like(local) for _ in range(world)]
         full = torch.empty((frames_total, HEIGHT, WIDTH), dtype=torch.int32, device="cuda")
-        row_index = [torch.as_tensor(ptr_amd.StripPart(world, r, STRIP).global_rows(HEIGHT), device="cuda")
-                     for r in range(world)]
+
+    # ---- N > 1: the library's communicator (RCCL), checked; torch.distributed is the channel for the id and the fallback
+    gather_mode = None
+    comm_stream = None
+    if world > 1:
+        ok = 1
+        try:
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                uid = torch.frombuffer(bytearray(rdr.comm_unique_id()), dtype=torch.uint8).clone()
+            uid = uid.cuda() if backend == "nccl" else uid
+            dist.broadcast(uid, src=0)
+            if backend != "nccl":
+                raise RuntimeError("rehearsal backend: ranks may share a GPU, which RCCL refuses")
+            rdr.comm_init_rank(bytes(uid.cpu().numpy().tobytes()), rank, world)
+        except Exception as e:                   # noqa: BLE001 - whatever went wrong, every rank has to learn of it
+            ok = 0
+            print(f"rank {rank}: library communicator not available ({e}); gathering with torch.distributed", file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        gather_mode = "library" if int(flag.item()) == 1 else "torch"
+        comm_stream = torch.cuda.Stream()
+    render_stream = torch.cuda.current_stream()
+    rendered = [torch.cuda.Event() for _ in range(n_buf)]
+    gathered_ev = [torch.cuda.Event() for _ in range(n_buf)]
+    gathered_t = [torch.empty_like(local) for _ in range(world)] if (world > 1 and rank == 0) else None
+    step_no = [0]
+
+    def gather_step(buf):
+        """on the communication stream: the strips of locals_[buf] of every rank -> whole frames on rank 0"""
+        if gather_mode == "library":
+            rdr.gather_strips_device(WIDTH, HEIGHT, STRIP, frames_total, locals_[buf].data_ptr(),
+                                     full.data_ptr() if rank == 0 else None, root=0,
+                                     frame_stride_px=max_rows * WIDTH, stream=comm_stream.cuda_stream)
+            return
+        if backend == "nccl":
+            dist.gather(locals_[buf], gathered_t, dst=0)
+        else:                                      # rehearsal: stage through the host
+            comm_stream.synchronize()
+            host = locals_[buf].cpu()
+            hl = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+            dist.gather(host, hl, dst=0)
+            if rank == 0:
+                for r in range(world):
+                    gathered_t[r].copy_(hl[r])
+        if rank == 0:                              # the library's copy kernel puts every part's rows at their places
+            for r in range(world):
+                rdr.place_strips_device(ptr_amd.StripPart(world, r, STRIP), WIDTH, HEIGHT, frames_total, gathered_t[r].data_ptr(),
+                                        full.data_ptr(), frame_stride_px=max_rows * WIDTH, stream=comm_stream.cuda_stream)
 
     def step(flags=0, gather=True):
         p.flags = flags
-        rdr.render_strips_device(p, part, 0, frames_total, local.data_ptr(), stream=stream,
+        buf = step_no[0] % n_buf
+        step_no[0] += 1
+        if world > 1:
+            render_stream.wait_event(gathered_ev[buf])          # the gather of two steps ago has read this buffer
+        rdr.render_strips_device(p, part, 0, frames_total, locals_[buf].data_ptr(), stream=stream,
                                  frame_stride_px=max_rows * WIDTH)
         if world > 1 and gather:
-            if backend == "nccl":
-                dist.gather(local, gathered, dst=0)
-            else:                                  # rehearsal: stage through the host
-                torch.cuda.synchronize()
-                host = local.cpu()
-                hl = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
-                dist.gather(host, hl, dst=0)
-                if rank == 0:
-                    for r in range(world):
-                        gathered[r].copy_(hl[r])
-            if rank == 0:
-                for r in range(world):
-                    full.index_copy_(1, row_index[r], gathered[r][:, : row_index[r].numel(), :])
+            rendered[buf].record(render_stream)
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(rendered[buf])
+                gather_step(buf)
+                gathered_ev[buf].record(comm_stream)
 
     def fence():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
+
+    # ---- N > 1: before anything is timed, rank 0's first gathered frames must equal single-GPU renders
+    if world > 1:
+        try:
+            step()
+            err = 0
+        except ptr_amd.PtrError as e:                # the library's gather refused: every rank must learn of it
+            print(f"rank {rank}: {e}", file=sys.stderr)
+            err = 1
+        flag = torch.tensor([err], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) and gather_mode == "library":
+            gather_mode = "torch (the library's gather raised an error)"
+            step()
+        fence()
+        good = 1
+        if rank == 0:
+            whole = torch.empty((HEIGHT, WIDTH), dtype=torch.int32, device="cuda")
+            for f in (0, frames_total - 1):
+                rdr.render_device(rdr.params(WIDTH, HEIGHT, flags=0), f, 1, whole.data_ptr(), stream=stream)
+                torch.cuda.synchronize()
+                good &= int(torch.equal(full[f], whole))
+        flag = torch.tensor([good], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+        dist.broadcast(flag, src=0)
+        if int(flag.item()) != 1 and gather_mode == "library":
+            if rank == 0:
+                print("the library's gather gave a wrong frame; falling back to torch.distributed", file=sys.stderr)
+            gather_mode = "torch (the library's gather failed its check)"
+            step(); fence()
+            if rank == 0:
+                good = int(torch.equal(full[0], whole) if frames_total == 1 else torch.equal(full[frames_total - 1], whole))
+            flag = torch.tensor([good], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+            dist.broadcast(flag, src=0)
+        if int(flag.item()) != 1:
+            raise SystemExit("gathered frame differs from the single-GPU frame")
 
     for _ in range(args.warmup):
         step()
@@ -235,6 +322,8 @@ def main():
     main_ms = float(np.mean([k[0] for k in kms]))
     retrace_ms = float(np.mean([k[1] for k in kms]))
 
+    if args.check and world > 1:                      # (a collective: every rank takes the step)
+        step(); fence()
     if args.check and rank == 0:
         whole = torch.empty((HEIGHT, WIDTH), dtype=torch.int32, device="cuda")
         rdr.render_device(rdr.params(WIDTH, HEIGHT, flags=0), 0, 1, whole.data_ptr(), stream=stream)
@@ -268,6 +357,69 @@ def main():
                   "dtype": "f32", "note": "extension mode, specification in include/ptr.h; not reference behaviour "
                                           "(parity vs the float64 specification: tests/test_gpu_ext.py)"}
 
+    # ---- N > 1: BASELINE.json configs[3]'s workload beside the headline (4K, 256 samples per pixel, depth 5, float32
+    # extension kernel, synthetic.config3_scene): one 4K frame's worth of pixels per GPU per step (`world` frames cut into
+    # strips), gathered the same way.  A pixel costs ~10^3 times its 4 bytes here, so this is the workload that can scale.
+    config3 = None
+    if world > 1:
+        from ptr_amd import synthetic as syn
+        W4, H4, SPP, SEED = 3840, 2160, 256, 0x5EED1234
+        r3 = ptr_amd.Renderer(local_rank)
+        r3.set_scene(np.ascontiguousarray(np.broadcast_to(syn.config3_scene(), (world, 12, 7))))
+        r3.set_background(syn.BACKGROUND)
+        part3 = ptr_amd.StripPart(world, rank, STRIP)
+        rows3, max3 = part3.local_rows(H4), ptr_amd.StripPart(world, 0, STRIP).local_rows(H4)
+        loc3 = torch.empty((world, max3, W4), dtype=torch.int32, device="cuda")
+        full3 = torch.empty((world, H4, W4), dtype=torch.int32, device="cuda") if rank == 0 else None
+        gat3 = [torch.empty_like(loc3) for _ in range(world)] if (rank == 0 and gather_mode != "library") else None
+        p3 = r3.params(W4, H4, 0, rows3, flags=ptr_amd.MODE_F32_ONLY, max_depth=5, spp=SPP, seed=SEED)
+
+        def step3():
+            r3.render_strips_device(p3, part3, 0, world, loc3.data_ptr(), stream=stream, frame_stride_px=max3 * W4)
+            if gather_mode == "library":
+                rdr.gather_strips_device(W4, H4, STRIP, world, loc3.data_ptr(), full3.data_ptr() if rank == 0 else None,
+                                         root=0, frame_stride_px=max3 * W4, stream=stream)
+            else:
+                if backend == "nccl":
+                    dist.gather(loc3, gat3, dst=0)
+                else:
+                    torch.cuda.synchronize()
+                    host = loc3.cpu()
+                    hl = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+                    dist.gather(host, hl, dst=0)
+                    if rank == 0:
+                        for r in range(world):
+                            gat3[r].copy_(hl[r])
+                if rank == 0:
+                    for r in range(world):
+                        rdr.place_strips_device(ptr_amd.StripPart(world, r, STRIP), W4, H4, world, gat3[r].data_ptr(),
+                                                full3.data_ptr(), frame_stride_px=max3 * W4, stream=stream)
+        for _ in range(2):
+            step3()
+        fence()
+        n3 = max(3, min(args.steps, 10))
+        t3 = time.perf_counter()
+        for _ in range(n3):
+            step3()
+        fence()
+        d3 = torch.tensor([time.perf_counter() - t3], dtype=torch.float64, device="cuda")
+        dist.all_reduce(d3, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            # rays per 4K frame from the work counters of a 1/16-size frame of the same picture (x 16), counted in float64
+            r3.render_device(r3.params(W4 // 4, H4 // 4, flags=ptr_amd.FLAG_STATS, max_depth=5, spp=SPP, seed=SEED), 0, 1,
+                             loc3.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            c3 = r3.stats()
+            rays3 = 16 * (c3["primary"] + c3["secondary"] + c3["shadow_rays"])
+            config3 = {"workload": f"BASELINE.json configs[3]: {W4}x{H4}, {SPP} spp, depth 5, {world} frames per step in cyclic "
+                                   f"{STRIP}-row strips over {world} GPUs (one frame's worth of pixels per GPU), gathered on rank 0",
+                       "value": round(rays3 * world * n3 / float(d3.item()) / 1e6, 1), "unit": "Mrays/s",
+                       "ms_per_step": round(float(d3.item()) / n3 * 1e3, 3), "rays_per_frame_estimate": rays3,
+                       "gathered_bytes_per_step_into_rank0": int(4 * W4 * H4 * world * (world - 1) / world),
+                       "dtype": "f32", "note": "extension mode (specification in include/ptr.h), not reference behaviour; "
+                                               "ray count scaled from a 960x540 counting run"}
+        r3.close()
+
     if rank == 0:
         share = local_rows / HEIGHT                      # fraction of every frame this rank renders
         total_rays = rays_per_frame * frames_total       # all ranks together, per step
@@ -286,7 +438,8 @@ def main():
                                    f"semantics (depth 0), {args.frames} frames per GPU per step, hybrid mode",
                        "frames_per_step": frames_total, "rays_per_frame": rays_per_frame,
                        "parallelism": "1 GPU" if world == 1 else
-                       f"{world} ranks, cyclic {STRIP}-row strips, RCCL gather to rank 0 in the timed region"},
+                       f"{world} ranks, cyclic {STRIP}-row strips, RCCL gather to rank 0 in the timed region, "
+                       f"overlapped with the next step's render"},
             "Mpixels_per_s": round(WIDTH * HEIGHT * frames_total * args.steps / elapsed / 1e6, 1),
             "roofline": {"bound": "valu", "kernel": "render_fast_kernel<hybrid>",
                          "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
@@ -308,10 +461,15 @@ def main():
             out["phases"] = {
                 "render_only_ms_per_step": round(render_only / args.steps * 1e3, 4),
                 "render_only_Mrays_per_s": round(total_rays * args.steps / render_only / 1e6, 1),
-                "gather_and_reinterleave_ms_per_step": round((elapsed - render_only) / args.steps * 1e3, 4),
+                "gather_not_hidden_ms_per_step": round((elapsed - render_only) / args.steps * 1e3, 4),
                 "gathered_bytes_per_step_into_rank0": int(4 * WIDTH * HEIGHT * frames_total * (world - 1) / world),
-                "note": "at 1 sample per pixel a GPU produces ~0.5 TB/s of pixels; the gather to rank 0 is bound by rank 0's "
-                        "inbound xGMI links, not by the renderers (DESIGN.md section 6)"}
+                "gather": gather_mode, "gather_overlapped_with_next_render": True,
+                "rank0_inbound_link_bound_ms_per_step": round(4 * WIDTH * HEIGHT * frames_total / world / 64e9 * 1e3, 3),
+                "note": "at 1 sample per pixel one GPU produces 0.8 TB/s of pixels; every peer's share of a step crosses ONE xGMI "
+                        "link into rank 0 (about 64 GB/s in one direction): the figure above is that link's time for a step, "
+                        "which no overlap can hide once it exceeds the render time (DESIGN.md section 6)"}
+            if config3 is not None:
+                out["config3_4k_256spp"] = config3
         if depth5 is not None:
             out["extension_depth5"] = depth5
         if world == 1 and not args.no_cpu_baseline:

@@ -200,9 +200,58 @@ typedef struct ptr_strips {
     int32_t reserved;      /* 0                                                                */
 } ptr_strips;
 int ptr_strip_rows(const ptr_strips *s, int height);
+/* image row of local row `local_row` of the part (the rule ptr_render_strips_device renders by and the gather places
+ * rows by); < 0: bad arguments.  No GPU needed: hosts that collect the parts themselves use it.                   */
+int ptr_strip_image_row(const ptr_strips *s, int local_row);
 int ptr_render_strips_device(ptr_ctx *ctx, const ptr_params *p, const ptr_strips *s,
                              int first_frame, int n_frames, void *d_rgba8, void *d_rgba32f,
                              uint64_t frame_stride_px, void *stream);
+
+/* ---- multi-GPU: collecting the parts of a frame on one GPU ------------------------------------------------------ */
+/* Replaces the collection of the workers' bands, RT/src/RenderPlanner.js:85-100 (onmessage -> onUpdateReceived) and
+ * RT/examples/example3.js:66-86 (pieces put side by side into the canvas): every GPU renders one part of the cyclic
+ * strip partition (ptr_render_strips_device) and the parts meet in ONE frame buffer on the root GPU, over RCCL
+ * (xGMI): a direct gather - every peer sends over its own link to the root, grouped ncclSend / ncclRecv - followed by
+ * one copy kernel on the root that puts the strips at their rows.  RCCL (librccl.so.1) is loaded when the first of
+ * these calls needs it; rendering on one GPU never touches it.
+ *
+ * A communicator joins the contexts of one job, one context per GPU:
+ *   one process per GPU (torchrun style): rank 0 calls ptr_comm_unique_id, hands the 128 bytes to the other
+ *     processes by whatever channel it has, and every process calls ptr_comm_init_rank on its context;
+ *   one process, several GPUs (the Node host): ptr_comm_init_all on the array of contexts (rank = index).
+ * n_ranks == 1 is allowed (nothing is sent).  ptr_destroy ends a context's membership; ptr_comm_destroy does so early. */
+#define PTR_COMM_ID_BYTES 128
+int ptr_comm_unique_id(unsigned char id[PTR_COMM_ID_BYTES]);
+int ptr_comm_init_rank(ptr_ctx *ctx, const unsigned char id[PTR_COMM_ID_BYTES], int rank, int n_ranks);
+int ptr_comm_init_all(ptr_ctx *const *ctxs, int n_ctxs);
+int ptr_comm_destroy(ptr_ctx *ctx);
+
+/* Gather on `stream` (enqueue only).  This context's rank is its part of the partition, the number of ranks the
+ * number of parts.  d_local: what ptr_render_strips_device wrote for this part - n_frames frames, frame_stride_px
+ * pixels apart (0 = the rows of part 0, the largest part, times width: the same value on every rank, as the equally
+ * sized messages need).  d_full (root only, others pass NULL): n_frames * height * width RGBA8 words, every row at its
+ * place.  The root keeps a staging buffer of (n_ranks - 1) local buffers, grown on demand.  Collective: every rank of
+ * the communicator calls it with the same sizes.                                                                  */
+int ptr_gather_strips_device(ptr_ctx *ctx, int width, int height, int strip_height, int n_frames,
+                             const void *d_local, uint64_t frame_stride_px, void *d_full, int root, void *stream);
+/* The copy step of the gather on its own, for hosts that move the parts themselves (another collective library, PCIe):
+ * the rows of part s->part, as ptr_render_strips_device wrote them at d_part (n_frames frames, frame_stride_px apart, 0 =
+ * this part's rows times width), go to their places in the whole frames at d_full.  No communicator needed.  Enqueues on
+ * `stream`.                                                                                                        */
+int ptr_place_strips_device(ptr_ctx *ctx, const ptr_strips *s, int width, int height, int n_frames,
+                            const void *d_part, uint64_t frame_stride_px, void *d_full, void *stream);
+/* The same for a communicator made by ptr_comm_init_all, all ranks from one thread: d_locals[i] belongs to
+ * ctxs[i], the root is ctxs[0], every part travels on its context's own stream (ptr_sync(ctxs[0]) waits for the frame). */
+int ptr_gather_strips_all(ptr_ctx *const *ctxs, int n_ctxs, int width, int height, int strip_height, int n_frames,
+                          const void *const *d_locals, uint64_t frame_stride_px, void *d_full);
+
+/* RayTracer.render for one frame on several GPUs, host buffer out - what RenderPlanner does with its workers
+ * (RT/src/RenderPlanner.js:27-47,85-100), in one call: ctxs[i] renders part i of the 8-row cyclic strip partition of frame
+ * 0 of ITS scene (the caller gives every context the same scene, background and camera, as RenderPlanner.js:61-74 sends
+ * them to every worker), the parts are gathered on ctxs[0]'s GPU and copied to out_rgba8 (width * height words).
+ * Needs a communicator over exactly these contexts (ptr_comm_init_all).  p->start_y must be 0, p->scan_height ==
+ * p->height, no PTR_QUIRK_ROW_SHIFT.  Synchronous.                                                                */
+int ptr_render_multi(ptr_ctx *const *ctxs, int n_ctxs, const ptr_params *p, uint32_t *out_rgba8);
 
 /* ptr_render_device for callers that cannot allocate.  No counterpart in the reference: it exists for callers that
  * may not call hipMalloc at this point - code under HIP graph capture, tight serving loops, harnesses that forbid it.

@@ -207,6 +207,15 @@ struct RcShadeArgs {
     double* pixel_age;                       // scratch owned by the context, grid: the element's age after culling
 };
 
+// multi-GPU gather, copy step on the root (ptr_kernels_gather.hip); device pointers
+struct GatherArgs {
+    const uint32_t* src;             // one part's rows, n_frames frames, src_frame_stride_px apart
+    uint32_t* full;                  // n_frames * height * width
+    uint64_t src_frame_stride_px;
+    int32_t width, height, n_frames;
+    int32_t strip_h, n_parts, part, rows;   // rows = local rows of this part
+};
+
 // image row of local row `row` (band: start_y + row; cyclic strips: strip k belongs to part k % n_parts)
 __host__ __device__ inline int global_y(const RenderArgs& a, int row)
 {

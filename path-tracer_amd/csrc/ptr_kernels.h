@@ -27,4 +27,7 @@ hipError_t launch_rc_shade(const RcShadeArgs& a, hipStream_t s);
 size_t rc_sort_temp_bytes(int n_items, int width, int height);
 hipError_t launch_rc_reproject(const RcArgs& a, void* sort_temp, size_t sort_temp_bytes, hipStream_t s);
 
+// multi-GPU gather: one part's compact rows -> their places in the whole frames (ptr_kernels_gather.hip)
+hipError_t launch_gather_rows(const GatherArgs& a, hipStream_t s);
+
 }  // namespace ptr

@@ -27,8 +27,10 @@ SYMBOLS = [
     "ptr_abi_version", "ptr_create", "ptr_destroy", "ptr_last_error",
     "ptr_set_scene", "ptr_set_scene_f64", "ptr_set_scene_sequence_f64",
     "ptr_set_background", "ptr_set_background_f64", "ptr_set_camera",
-    "ptr_render", "ptr_render_device", "ptr_render_device_noalloc", "ptr_render_strips_device", "ptr_strip_rows", "ptr_sync",
+    "ptr_render", "ptr_render_device", "ptr_render_device_noalloc", "ptr_render_strips_device", "ptr_strip_rows", "ptr_strip_image_row", "ptr_sync",
     "ptr_trace_batch", "ptr_trace_batch_f64", "ptr_trace_samples_f64", "ptr_rc_reproject", "ptr_rc_reproject_device", "ptr_rc_shade", "ptr_rc_shade_device", "ptr_get_stats", "ptr_get_kernel_ms",
+    "ptr_comm_unique_id", "ptr_comm_init_rank", "ptr_comm_init_all", "ptr_comm_destroy",
+    "ptr_gather_strips_device", "ptr_gather_strips_all", "ptr_place_strips_device", "ptr_render_multi",
 ]
 
 
@@ -66,6 +68,9 @@ class StripPart:
 
     def local_rows(self, height):
         return lib().ptr_strip_rows(C.byref(self.c), height)
+
+    def image_row(self, local_row):
+        return lib().ptr_strip_image_row(C.byref(self.c), local_row)
 
     def global_rows(self, height):
         sh, n, part = self.c.strip_height, self.c.n_parts, self.c.part
@@ -127,6 +132,7 @@ def lib():
         L.ptr_render_strips_device.argtypes = [vp, C.POINTER(Params), C.POINTER(Strips), C.c_int, C.c_int,
                                                vp, vp, C.c_uint64, vp]
         L.ptr_strip_rows.argtypes = [C.POINTER(Strips), C.c_int]
+        L.ptr_strip_image_row.argtypes = [C.POINTER(Strips), C.c_int]
         L.ptr_sync.argtypes = [vp]
         L.ptr_trace_batch.argtypes = [vp, fp, C.c_int, C.POINTER(C.c_uint8), fp, fp]
         L.ptr_trace_batch_f64.argtypes = [vp, dp, dp, C.c_int, dp, C.POINTER(C.c_int32), dp, dp]
@@ -137,6 +143,14 @@ def lib():
         up = C.POINTER(C.c_uint32)
         L.ptr_rc_shade.argtypes = [vp, C.POINTER(RcShadeParams), C.c_int, ip, dp, dp, up, up, ip, up, dp, up, up, up]
         L.ptr_rc_shade_device.argtypes = [vp, C.POINTER(RcShadeParams), C.c_int] + [vp] * 12
+        L.ptr_comm_unique_id.argtypes = [C.POINTER(C.c_ubyte)]
+        L.ptr_comm_init_rank.argtypes = [vp, C.POINTER(C.c_ubyte), C.c_int, C.c_int]
+        L.ptr_comm_init_all.argtypes = [C.POINTER(vp), C.c_int]
+        L.ptr_comm_destroy.argtypes = [vp]
+        L.ptr_gather_strips_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_uint64, vp, C.c_int, vp]
+        L.ptr_gather_strips_all.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.c_uint64, vp]
+        L.ptr_place_strips_device.argtypes = [vp, C.POINTER(Strips), C.c_int, C.c_int, C.c_int, vp, C.c_uint64, vp, vp]
+        L.ptr_render_multi.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(Params), C.POINTER(C.c_uint32)]
         L.ptr_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.ptr_get_kernel_ms.argtypes = [vp, fp, fp]
         _lib = L
@@ -161,6 +175,28 @@ def scene_to_soa(elements):
 
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def render_multi(renderers, width, height, flags=0, max_depth=0, spp=1, seed=0):
+    """ptr_render_multi over Renderer objects that share a communicator (comm_init_all): one frame, host array out"""
+    L = lib()
+    n = len(renderers)
+    hs = (C.c_void_p * n)(*[r._h for r in renderers])
+    p = Params(width, height, 0, height, max_depth, spp, seed, flags)
+    out = np.empty(width * height, dtype=np.uint32)
+    rc = L.ptr_render_multi(hs, n, C.byref(p), out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    if rc != OK:
+        raise PtrError(rc, L.ptr_last_error(renderers[0]._h).decode())
+    return out
+
+
+def comm_init_all(renderers):
+    L = lib()
+    n = len(renderers)
+    hs = (C.c_void_p * n)(*[r._h for r in renderers])
+    rc = L.ptr_comm_init_all(hs, n)
+    if rc != OK:
+        raise PtrError(rc, L.ptr_last_error(renderers[0]._h).decode())
 
 
 class Renderer:
@@ -351,6 +387,30 @@ class Renderer:
                                             hit.ctypes.data_as(fp) if want_hit else None,
                                             nrm.ctypes.data_as(fp) if want_hit else None))
         return (rgb, hit, nrm) if want_hit else rgb
+
+    # ---- multi-GPU
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes from ncclGetUniqueId (rank 0 makes it, every rank gets it by the job's own channel)"""
+        L = lib()
+        buf = (C.c_ubyte * 128)()
+        rc = L.ptr_comm_unique_id(buf)
+        if rc != OK:
+            raise PtrError(rc, L.ptr_last_error(None).decode())
+        return bytes(buf)
+
+    def comm_init_rank(self, uid, rank, n_ranks):
+        buf = (C.c_ubyte * 128).from_buffer_copy(uid) if uid is not None else None
+        self._check(self._L.ptr_comm_init_rank(self._h, buf, rank, n_ranks))
+
+    def gather_strips_device(self, width, height, strip_height, n_frames, d_local, d_full, root=0, frame_stride_px=0, stream=None):
+        self._check(self._L.ptr_gather_strips_device(self._h, width, height, strip_height, n_frames, C.c_void_p(d_local),
+                                                     frame_stride_px, C.c_void_p(d_full) if d_full else None, root,
+                                                     C.c_void_p(stream) if stream else None))
+
+    def place_strips_device(self, part, width, height, n_frames, d_part, d_full, frame_stride_px=0, stream=None):
+        self._check(self._L.ptr_place_strips_device(self._h, C.byref(part.c), width, height, n_frames, C.c_void_p(d_part),
+                                                    frame_stride_px, C.c_void_p(d_full), C.c_void_p(stream) if stream else None))
 
     def kernel_ms(self):
         a, b = C.c_float(), C.c_float()

@@ -304,3 +304,61 @@ def test_long_odd_sequence_three_calls_in_a_row(scenes):
         assert float(f32[nf - 1, 0, 0, 3]) == 1.0
     finally:
         r.close()
+
+
+def test_library_gather_on_one_gpu(scenes):
+    """the multi-GPU entry points as far as ONE GPU can take them: a one-rank communicator (nothing is sent), the gather's
+    copy step placing the parts of a 3-way partition rendered one after the other, ptr_render_multi on one context, and
+    the argument checks.  (The ncclSend / ncclRecv leg needs several GPUs: bench.py --gpus N checks it against
+    torch.distributed's gather at start-up.)"""
+    torch = pytest.importorskip("torch")
+    sc = scenes["example1"]
+    soa = ptr_amd.scene_to_soa(sc["elements"])
+    moved = soa.copy(); moved[1, 1] = 1.5
+    w, h, nf = 200, 77, 2
+    want = [orc.render(s, sc["background"], w, h, flags=0).reshape(h, w) for s in (soa, moved)]
+    r = ptr_amd.Renderer(0)
+    try:
+        r.set_scene(np.stack([soa, moved])); r.set_background(sc["background"])
+        full = torch.zeros((nf, h, w), dtype=torch.int32, device="cuda")
+        n_parts = 3
+        max_rows = ptr_amd.StripPart(n_parts, 0, 8).local_rows(h)
+        for part in range(n_parts):
+            sp = ptr_amd.StripPart(n_parts, part, 8)
+            rows = sp.local_rows(h)
+            local = torch.full((nf, max_rows, w), 0x7F7F7F7F, dtype=torch.int32, device="cuda")
+            r.render_strips_device(r.params(w, h, 0, rows, flags=0), sp, 0, nf, local.data_ptr(), frame_stride_px=max_rows * w)
+            r.place_strips_device(sp, w, h, nf, local.data_ptr(), full.data_ptr(), frame_stride_px=max_rows * w)
+            r.sync()
+        got = full.cpu().numpy().view(np.uint32)
+        for f in range(nf):
+            assert np.array_equal(got[f], want[f]), f
+        # a communicator of one rank: the gather is the copy step alone; odd width -> the one-pixel-per-lane form
+        with pytest.raises(ptr_amd.PtrError):
+            r.gather_strips_device(w, h, 8, nf, full.data_ptr(), full.data_ptr())          # no communicator yet
+        r.comm_init_rank(None, 0, 1)
+        with pytest.raises(ptr_amd.PtrError):
+            r.comm_init_rank(None, 0, 1)                                                   # already a member
+        w2 = 199
+        local = torch.empty((nf, h, w2), dtype=torch.int32, device="cuda")
+        full2 = torch.zeros((nf, h, w2), dtype=torch.int32, device="cuda")
+        r.render_device(r.params(w2, h, flags=0), 0, nf, local.data_ptr())
+        r.gather_strips_device(w2, h, 8, nf, local.data_ptr(), full2.data_ptr(), root=0)
+        r.sync()
+        assert torch.equal(local, full2)
+        with pytest.raises(ptr_amd.PtrError):
+            r.gather_strips_device(w2, h, 8, nf, local.data_ptr(), full2.data_ptr(), root=1)
+        one = ptr_amd.render_multi([r], w, h)                                               # frame 0, whole, host array
+        assert np.array_equal(one.reshape(h, w), want[0])
+    finally:
+        r.close()
+    a, b = ptr_amd.Renderer(0), ptr_amd.Renderer(0)
+    try:
+        with pytest.raises(ptr_amd.PtrError) as e:                                         # two ranks on one GPU
+            ptr_amd.comm_init_all([a, b])
+        assert "same GPU" in str(e.value)
+        ptr_amd.comm_init_all([a])
+        a.set_scene(soa); a.set_background(sc["background"])
+        assert np.array_equal(ptr_amd.render_multi([a], w, h).reshape(h, w), want[0])
+    finally:
+        a.close(); b.close()

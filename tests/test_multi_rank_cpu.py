@@ -37,7 +37,10 @@ def _worker(rank, world, port, strip, w, h, ret):
         full = torch.zeros((h, w), dtype=torch.int32)
         seen = np.zeros(h, dtype=np.int32)
         for r in range(world):
-            idx = ptr_amd.StripPart(world, r, strip).global_rows(h)
+            sp = ptr_amd.StripPart(world, r, strip)
+            idx = sp.global_rows(h)
+            # the row rule the library's own gather places by (ptr_strip_image_row) == the Python mirror
+            assert [sp.image_row(k) for k in range(len(idx))] == idx
             seen[idx] += 1
             full.index_copy_(0, torch.as_tensor(idx), gathered[r][: len(idx)])
         want = orc.render(soa, bg, w, h, flags=0).reshape(h, w)
