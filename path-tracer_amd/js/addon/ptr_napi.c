@@ -17,6 +17,8 @@
  *   traceBatch(h, Float64Array origins | null, Float64Array dirs)
  *        -> { rgb: Float64Array, element: Int32Array, hit: Float64Array, normal: Float64Array }
  *                                                                            ptr_trace_batch_f64
+ *   commInitAll([h...])                                                      ptr_comm_init_all
+ *   renderMulti([h...], w, height, flags[, maxDepth, spp, seed]) -> ArrayBuffer   ptr_render_multi
  *   stats(h) -> { primary, hits, shadowRays, exitTca, exitD2, exitHit, retraced, reshaded }   ptr_get_stats
  */
 #include <node_api.h>
@@ -541,6 +543,62 @@ static napi_value js_rc_shade(napi_env env, napi_callback_info info)
     return out;
 }
 
+/* handles: a JS array of renderer handles -> ptr_ctx*[] (at most 64); 0 on a bad argument (exception pending) */
+static int get_ctx_array(napi_env env, napi_value arr, ptr_ctx **out, uint32_t *n)
+{
+    bool is_arr = false;
+    if (napi_is_array(env, arr, &is_arr) != napi_ok || !is_arr || napi_get_array_length(env, arr, n) != napi_ok || *n < 1 || *n > 64) {
+        napi_throw_type_error(env, NULL, "expected an array of 1..64 renderer handles");
+        return 0;
+    }
+    for (uint32_t k = 0; k < *n; k++) {
+        napi_value v;
+        if (napi_get_element(env, arr, k, &v) != napi_ok) return 0;
+        out[k] = get_ctx(env, v);
+        if (!out[k]) return 0;
+    }
+    return 1;
+}
+
+/* commInitAll(handles): one RCCL communicator over the renderers of one job, one per GPU (ptr_comm_init_all) */
+static napi_value js_comm_init_all(napi_env env, napi_callback_info info)
+{
+    napi_value argv[1];
+    ptr_ctx *ctxs[64]; uint32_t n;
+    if (!get_args(env, info, 1, argv) || !get_ctx_array(env, argv[0], ctxs, &n)) return NULL;
+    int rc = ptr_comm_init_all(ctxs, (int)n);
+    if (rc != PTR_OK) return throw_ptr(env, ctxs[0], rc);
+    return NULL;
+}
+
+/* renderMulti(handles, width, height, flags[, maxDepth, spp, seed]) -> ArrayBuffer: one whole frame rendered in cyclic
+ * strips on all the renderers' GPUs and gathered on the first one's (ptr_render_multi) */
+static napi_value js_render_multi(napi_env env, napi_callback_info info)
+{
+    napi_value argv[7];
+    ptr_ctx *ctxs[64]; uint32_t n;
+    if (!get_args_opt(env, info, 4, 7, argv) || !get_ctx_array(env, argv[0], ctxs, &n)) return NULL;
+    ptr_params p;
+    int32_t flags;
+    memset(&p, 0, sizeof p);
+    if (!get_i32(env, argv[1], &p.width) || !get_i32(env, argv[2], &p.height) || !get_i32(env, argv[3], &flags)) return NULL;
+    p.scan_height = p.height; p.flags = (uint32_t)flags; p.spp = 1;
+    napi_valuetype t;
+    if (napi_typeof(env, argv[4], &t) == napi_ok && t != napi_undefined && !get_i32(env, argv[4], &p.max_depth)) return NULL;
+    if (napi_typeof(env, argv[5], &t) == napi_ok && t != napi_undefined && !get_i32(env, argv[5], &p.spp)) return NULL;
+    if (napi_typeof(env, argv[6], &t) == napi_ok && t != napi_undefined && napi_get_value_uint32(env, argv[6], &p.seed) != napi_ok) {
+        napi_throw_type_error(env, NULL, "seed must be an unsigned 32-bit integer");
+        return NULL;
+    }
+    if (!check_frame_size(env, &p)) return NULL;
+    void *data = NULL;
+    napi_value buf;
+    NAPI_TRY(env, napi_create_arraybuffer(env, (size_t)p.width * (size_t)p.height * 4, &data, &buf));
+    int rc = ptr_render_multi(ctxs, (int)n, &p, (uint32_t *)data);
+    if (rc != PTR_OK) return throw_ptr(env, ctxs[0], rc);
+    return buf;
+}
+
 static napi_value js_stats(napi_env env, napi_callback_info info)
 {
     napi_value argv[1];
@@ -567,6 +625,7 @@ NAPI_MODULE_INIT()
         {"create", js_create}, {"destroy", js_destroy}, {"setScene", js_set_scene},
         {"setBackground", js_set_background}, {"setCamera", js_set_camera}, {"render", js_render},
         {"renderAsync", js_render_async}, {"traceBatch", js_trace_batch}, {"traceSamples", js_trace_samples}, {"rcReproject", js_rc_reproject}, {"rcShade", js_rc_shade}, {"stats", js_stats},
+        {"commInitAll", js_comm_init_all}, {"renderMulti", js_render_multi},
     };
     for (size_t k = 0; k < sizeof fns / sizeof fns[0]; k++) {
         napi_value f;

@@ -34,7 +34,8 @@ export default class RayTracer {
         this.scene = scene;
         this.camera = camera;
         this._native = native();
-        this._handle = this._native.create(options.device | 0);
+        this._device = options.device | 0;
+        this._handle = this._native.create(this._device);
         const modes = { hybrid: 0, exact: this._native.MODE_EXACT_F64, f32: this._native.MODE_F32_ONLY };
         const mode = options.mode === undefined ? 'hybrid' : options.mode;
         if (!(mode in modes)) throw new TypeError(`unknown mode ${mode}`);

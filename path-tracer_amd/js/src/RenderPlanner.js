@@ -79,6 +79,28 @@ export default class RenderPlanner {
         });
     }
 
+    /**
+     * One whole frame (every row at its place, no row quirk) rendered on ALL the planner's GPUs at once: the frame is dealt
+     * out in cyclic strips of 8 rows, one part per device, and the parts meet on the first device over RCCL (xGMI) before one
+     * copy to the host - the collection that raytracer-js-master/examples/example3.js:66-86 does piece by piece with
+     * putImageData.  Uses the scene snapshot of the last initialize() / updateScene().  Returns an ArrayBuffer.
+     */
+    renderFrameGathered(options = {}) {
+        const first = [];
+        const seen = new Set();
+        for (const w of this.workers) {              // one renderer per distinct GPU, in device order of appearance
+            if (seen.has(w.tracer._device)) continue;
+            seen.add(w.tracer._device);
+            first.push(w);
+        }
+        for (const w of first) w.tracer._upload();
+        const handles = first.map(w => w.tracer._handle);
+        const native = first[0].tracer._native;
+        if (!this._comm) { native.commInitAll(handles); this._comm = true; }
+        return native.renderMulti(handles, this.width, this.height, first[0].tracer._modeFlags,
+                                  options.maxDepth, options.spp, options.seed);
+    }
+
     isRunning() { return this.running; }
 
     updateScene() {

@@ -398,6 +398,18 @@ async function gpuTests() {
             for (const buf of await Promise.all(pending)) assert.ok(sameBytes(new Uint8Array(buf), u8(m.file)));
         }
     });
+    test('RenderPlanner.renderFrameGathered(): cyclic strips over the planner\'s GPUs, gathered by the library (one GPU here)', () => {
+        const scene = buildExample1();
+        const planner = new RenderPlanner(4, scene, new Vector3(2, 2, 2), 200, 77, { devices: [0] });
+        planner.initialize();
+        const rt = new RayTracer(new Vector3(2, 2, 2), scene);
+        const want = new Uint8Array(rt.renderFrame(200, 77));
+        assert.ok(sameBytes(new Uint8Array(planner.renderFrameGathered()), want));
+        scene.getElements()[1].center = new Vector3(0, 2, -20);
+        planner.updateScene();
+        assert.ok(sameBytes(new Uint8Array(planner.renderFrameGathered()), new Uint8Array(rt.renderFrame(200, 77))));
+        rt.dispose(); planner.dispose();
+    });
     test('stats(): the reference ray mix at 640x480 (SURVEY 6)', () => {
         const rt = new RayTracer(new Vector3(2, 2, 2), buildExample1());
         rt.render(640, 480);
