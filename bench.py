@@ -67,6 +67,22 @@ def algorithmic_flops(st):
             + 33 * st["hits"] + 31 * st["shadow_rays"])
 
 
+def algorithmic_flops_ext(st, n_lights):
+    """The same counting rule for the extension modes' specification (include/ptr.h), from the work counters of the
+    float64 counting run: 30 per pixel (ray generation + pack); every traced ray's sphere tests 8 / 15 / 19 by exit; per
+    hit 24 (hit frame) + 6 (w * emission); per miss 6 (w * background); a hit that shades: 6 (shadow origin) + 31 per
+    light + 6 (w * sum); a hit that bounces: 11 (facing, fresnel, w * surfaceColor) + 38 for the reflection ray
+    (direction 7, normalize 10, origin 6, weight 3, ...) and 43 for a refraction ray.  Derived counts: shading hits =
+    shadow rays / lights, bouncing hits = hits - shading hits = reflection rays, refraction rays = secondary - reflection."""
+    rays = st["primary"] + st["secondary"]
+    hits = st["hits"]
+    shading = st["shadow_rays"] // max(1, n_lights)
+    bouncing = hits - shading
+    refraction = st["secondary"] - bouncing
+    return (30 * st["primary"] + 8 * st["exit_tca"] + 15 * st["exit_d2"] + 19 * st["exit_hit"] + 30 * hits + 6 * (rays - hits)
+            + 12 * shading + 31 * st["shadow_rays"] + 49 * bouncing + 43 * refraction)
+
+
 def cpu_baseline(soa, bg, seconds=12.0):
     """The CPU oracle (float64 C restatement of the reference) on this host's cores, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -350,12 +366,27 @@ def main():
             rdr.render_device(p5, 0, frames_total, local.data_ptr(), stream=stream)
         torch.cuda.synchronize()
         dt5 = time.perf_counter() - t5
+        p5.flags = ptr_amd.MODE_F32_ONLY | ptr_amd.FLAG_TIMING
+        k5 = []
+        for _ in range(3):
+            rdr.render_device(p5, 0, frames_total, local.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            k5.append(rdr.kernel_ms()[0])
+        flops5 = algorithmic_flops_ext(st5, 2) * frames_total
+        ach5 = flops5 / (float(np.mean(k5)) * 1e-3) / 1e12
         depth5 = {"workload": f"BASELINE.json configs[1]: example1 {WIDTH}x{HEIGHT}, depth 5, 1 spp, {frames_total} frames per step",
                   "value": round(rays5 * frames_total * n5 / dt5 / 1e6, 1), "unit": "Mrays/s",
                   "ms_per_step": round(dt5 / n5 * 1e3, 4), "rays_per_frame": rays5,
                   "camera_rays": st5["primary"], "secondary_rays": st5["secondary"], "shadow_rays": st5["shadow_rays"],
-                  "dtype": "f32", "note": "extension mode, specification in include/ptr.h; not reference behaviour "
-                                          "(parity vs the float64 specification: tests/test_gpu_ext.py)"}
+                  "roofline": {"bound": "valu", "kernel": "render_ext_kernel<float>", "achieved": round(ach5, 3),
+                               "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": round(ach5 / PEAK_FP32_VALU_TFLOPS, 4),
+                               "kernel_ms": round(float(np.mean(k5)), 4), "algorithmic_flops_per_launch": int(flops5),
+                               "traffic": None,
+                               "note": "algorithmic FLOPs of the specification's control flow (bench.py algorithmic_flops_ext) / "
+                                       "the kernel's own time (HIP events); HBM traffic: profiles/r02_summary.md"},
+                  "dtype": "f32", "note": "extension mode in its float32 throughput form (PTR_MODE_F32_ONLY; the default mode "
+                                          "renders the float64 specification), specification in include/ptr.h; not reference "
+                                          "behaviour (parity vs the specification: tests/test_gpu_ext.py)"}
 
     # ---- N > 1: BASELINE.json configs[3]'s workload beside the headline (4K, 256 samples per pixel, depth 5, float32
     # extension kernel, synthetic.config3_scene): one 4K frame's worth of pixels per GPU per step (`world` frames cut into

@@ -80,9 +80,10 @@ typedef struct ptr_ctx ptr_ctx;
  *   spp > 1: sample s of pixel (x, y) goes through (x + u0, y + u1), (u0, u1) = the first two words
  *   of Philox4x32-10(counter (x, y, s, 0), key (seed, 0x50545221)), u = (word + 0.5) / 2^32; the
  *   pixel is the mean of the samples (summed in sample order, one divide), then packed as ever.
- * With max_depth 0 and spp 1 a call has the reference semantics.  In the extension modes PTR_MODE_EXACT_F64 renders that specification bit
- * for bit, any other mode renders it in float32 (tolerance: see tests/test_gpu_ext.py);
- * PTR_QUIRK_ROW_SHIFT is rejected.                                       */
+ * With max_depth 0 and spp 1 a call has the reference semantics.  In the extension modes the default (no mode bit) and
+ * PTR_MODE_EXACT_F64 render that specification bit for bit in float64; PTR_MODE_F32_ONLY renders it in float32, the
+ * throughput form (tolerance: see tests/test_gpu_ext.py - PSNR > 50 dB, but single pixels on discontinuities and their
+ * mirror images can be off by more than 1/255, which is why it is not the default); PTR_QUIRK_ROW_SHIFT is rejected.  */
 #define PTR_MAX_DEPTH_LIMIT 16
 #define PTR_MAX_SPP         65536
 typedef struct ptr_params {

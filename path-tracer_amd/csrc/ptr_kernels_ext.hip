@@ -188,7 +188,41 @@ __device__ V<T> trace_ext(const SceneT<T>& sc, V<T> o0, V<T> d0, int max_depth, 
 typedef const f4 PTR_CONST* ConstRec;
 __device__ __forceinline__ bool any_lane_x(bool c) { return ballot(c) != 0ull; }
 
-__device__ V<float> trace_ext_f32(const unsigned char* block, const RenderArgs& a, V<float> o0, V<float> d0, int max_depth)
+// The stack of rays that wait (second children only: the reflection stays in registers).  Its entries have strictly
+// increasing depths from bottom to top, so max_depth entries per lane are enough.  The lowest PTR_EXT_LDS_ENTRIES of them
+// live in LDS, [entry][word][lane] (a lane's words are 256 bytes apart: every access is conflict-free), 2 560 bytes per entry
+// and wave: nothing of them ever reaches HBM.  A full-depth LDS image would leave three waves per SIMD at depth 5 (measured
+// 42 % slower), so the rare deeper entries (a chain of internal reflections inside a transparent sphere) go to a per-lane
+// array in scratch memory.
+#ifndef PTR_EXT_LDS_ENTRIES
+#define PTR_EXT_LDS_ENTRIES 2
+#endif
+struct RayStack {
+    float* base;       // this lane's first word in LDS
+    ExtRay<float> deep[PTR_EXT_MAX_DEPTH + 2 - PTR_EXT_LDS_ENTRIES];
+    __device__ __forceinline__ void push(int at, const ExtRay<float>& c)
+    {
+        if (at < PTR_EXT_LDS_ENTRIES) {
+            float* p = base + at * 640;
+            p[0] = c.o.x; p[64] = c.o.y; p[128] = c.o.z; p[192] = c.d.x; p[256] = c.d.y; p[320] = c.d.z;
+            p[384] = c.w.x; p[448] = c.w.y; p[512] = c.w.z; p[576] = __int_as_float(c.depth);
+        } else {
+            deep[at - PTR_EXT_LDS_ENTRIES] = c;
+        }
+    }
+    __device__ __forceinline__ ExtRay<float> pop(int at) const
+    {
+        if (at < PTR_EXT_LDS_ENTRIES) {
+            const float* p = base + at * 640;
+            return ExtRay<float>{V<float>{p[0], p[64], p[128]}, V<float>{p[192], p[256], p[320]}, V<float>{p[384], p[448], p[512]},
+                                 __float_as_int(p[576])};
+        }
+        return deep[at - PTR_EXT_LDS_ENTRIES];
+    }
+};
+
+template <typename Stack>
+__device__ V<float> trace_ext_f32(Stack& stack, const unsigned char* block, const RenderArgs& a, V<float> o0, V<float> d0, int max_depth)
 {
     const ConstHeader hdr = (ConstHeader)(uintptr_t)block;
     const ConstF4 recv0 = (ConstF4)(uintptr_t)(block + a.off_p32);      // the same table through loads that stay where they are written
@@ -201,15 +235,14 @@ __device__ V<float> trace_ext_f32(const unsigned char* block, const RenderArgs& 
     constexpr float BIAS = (float)PTR_BIAS;
 
     // Depth-first expansion with the ray that would be popped next kept in registers: a hit that spawns only a
-    // reflection (the usual case) never touches the stack, which lives in scratch memory; the order of the rays, and
-    // with it the order of the sums, is the specification's.
-    ExtRay<float> stack[PTR_EXT_MAX_DEPTH + 2];
+    // reflection (the usual case) never touches the stack; the order of the rays, and with it the order of the sums, is
+    // the specification's.
     int top = 0;
     ExtRay<float> r{o0, d0, V<float>{1, 1, 1}, 0};
     bool have = true;
     float ax = 0.0f, ay = 0.0f, az = 0.0f;
     while (have || top > 0) {
-        if (!have) r = stack[--top];
+        if (!have) r = stack.pop(--top);
         have = false;
         // nearest hit (RayTracer.js:26-41)
         float tnear = (float)PTR_INFINITY;
@@ -270,7 +303,7 @@ __device__ V<float> trace_ext_f32(const unsigned char* block, const RenderArgs& 
                 const float cosi = -dn;
                 const float k2 = 1.0f - eta * eta * (1.0f - cosi * cosi);
                 if (k2 >= 0.0f) {
-                    ExtRay<float>& c = stack[top++];
+                    ExtRay<float> c;
                     const float g = eta * cosi - __builtin_sqrtf(k2);
                     const float wt = (1.0f - fresnel) * transp;
                     c.o = V<float>{fmaf(-N.x, BIAS, P.x), fmaf(-N.y, BIAS, P.y), fmaf(-N.z, BIAS, P.z)};
@@ -279,6 +312,7 @@ __device__ V<float> trace_ext_f32(const unsigned char* block, const RenderArgs& 
                     c.d = V<float>{cd.x * inv, cd.y * inv, cd.z * inv};
                     c.w = V<float>{wx * wt, wy * wt, wz * wt};
                     c.depth = r.depth + 1;
+                    stack.push(top++, c);
                 }
             }
             // the reflection is the ray processed next (it would be pushed last and popped first): it stays in r
@@ -392,8 +426,11 @@ __device__ __forceinline__ void render_ext_pixel(const RenderArgs& a, int x, int
         xcount<STATS>(k, XT_CAMERA);
         V<T> c;
         if constexpr (sizeof(T) == 4 && !STATS) {
-            const V<float> cf = trace_ext_f32(a.scenes + (uint64_t)(a.first_frame + frame) * a.frame_stride, a,
-                                              V<float>{0, 0, 0}, V<float>{(float)d.x, (float)d.y, (float)d.z}, a.max_depth);
+            const unsigned char* block = a.scenes + (uint64_t)(a.first_frame + frame) * a.frame_stride;
+            __shared__ float ext_lds[PTR_EXT_LDS_ENTRIES * 640];          // (the float32 form runs one wave per workgroup)
+            RayStack st;
+            st.base = ext_lds + (threadIdx.x & 63);
+            const V<float> cf = trace_ext_f32(st, block, a, V<float>{0, 0, 0}, V<float>{(float)d.x, (float)d.y, (float)d.z}, a.max_depth);
             c = V<T>{T(cf.x), T(cf.y), T(cf.z)};
         } else {
             c = trace_ext<T, STATS>(sc, origin, d, a.max_depth, k);

@@ -191,7 +191,10 @@ async function gpuTests() {
         assert.throws(() => rt.renderFrame(64, 48, { maxDepth: 17 }), RangeError);
         assert.throws(() => rt.renderFrame(64, 48, { spp: 0 }), RangeError);
         rt.dispose();
-        const f32 = new RayTracer(new Vector3(2, 2, 2), buildExample1());
+        const f32 = new RayTracer(new Vector3(2, 2, 2), buildExample1(), undefined, { mode: 'f32' });   // the float32 throughput form, by name
+        const dflt = new RayTracer(new Vector3(2, 2, 2), buildExample1());                              // the default mode renders the specification
+        assert.ok(sameBytes(new Uint8Array(dflt.renderFrame(c.width, c.height, { maxDepth: 5, spp: 4, seed: 7 })), u8(c.file)));
+        dflt.dispose();
         const a = new Uint8Array(f32.renderFrame(c.width, c.height, { maxDepth: 5, spp: 4, seed: 7 })), b = u8(c.file);
         let off = 0;
         for (let i = 0; i < a.length; i++) if (Math.abs(a[i] - b[i]) > 1) off++;
