@@ -167,6 +167,27 @@ int ptr_set_background_f64(ptr_ctx *ctx, const double rgb[3]);
 /* cam == NULL restores the reference's fixed camera (RT/src/RayTracer.js:150-155).            */
 int ptr_set_camera(ptr_ctx *ctx, const ptr_camera *cam);
 
+/* Planes and Phong terms: EXTENSION scene data.  north_star names a ray-plane primitive and Phong shading; the reference
+ * has neither (its only primitive is RT/src/Sphere.js:15-33, its shading Lambert, RT/src/RayTracer.js:87-89; SURVEY.md
+ * F2), so, like the bounce loop, this is specified here and self-pinned (tests/golden/ext, "parity unpinned").  A scene
+ * with planes or Phong terms is rendered by the extension kernels whatever max_depth / spp are; RayTracer.render's
+ * reference path is untouched without them.  Specification (float64, evaluated left to right, on top of ptr_params'):
+ *   elements = the spheres in scene order, then the planes (element n_spheres + k).  Plane k = point p, UNIT normal n.
+ *   Plane.intersect(o, d):  denom = d.n;  denom == 0: miss;  t = ((p - o).n) / denom;  t < 0: miss;  else t0 = t
+ *   nearest hit: all spheres, then all planes, strict <.  A plane hit's normal is n (then turned to face the ray, which
+ *     sets `inside`, like any other).  Shadow rays test the planes too, after the spheres, but a plane blocks only IN FRONT of
+ *     the light: t0*t0 < |C_i - P|^2 (the squared length normalize() computes; a sphere keeps the reference's distance-blind
+ *     any-hit rule, RayTracer.js:74-85 - for an infinite plane that rule would darken everything that faces it).  A plane
+ *     with emission > 0 is a light at p.  Lights: emissive spheres in scene order, then emissive planes.
+ *   Phong: element e has ks >= 0 and an integer exponent m in 1..65536.  In the Lambert sum, after light i's diffuse term:
+ *     if ks > 0:  Rv = d - N*(2*(d.N));  s = max(0, Rv.L);  ph = 1; b = s; q = m; while q > 0 { if q odd: ph = ph*b;  b = b*b;
+ *       q >>= 1 };  dif += tr * (emission_i * (ks * ph))      (per channel; tr = the light's transmission, 0 or 1)
+ * planes_soa = 14 rows of n_planes values: px py pz nx ny nz  sr sg sb  reflection transparency  er eg eb (NULL / 0: no
+ * planes).  phong = ks[n_elements] then exponent[n_elements], n_elements = n_spheres + n_planes as they are at the next
+ * render (NULL: no Phong terms).  Replaces the previous extension data as a whole; (NULL, 0, NULL, 0) clears it.
+ * The single-ray entries (ptr_trace_*) refuse scenes with extension data.                                        */
+int ptr_set_extension_f64(ptr_ctx *ctx, const double *planes_soa, int n_planes, const double *phong, int n_elements);
+
 /* ---- render ------------------------------------------------------------------------------ */
 
 /* Replaces RayTracer.render() (RT/src/RayTracer.js:132-197): ray generation, trace, clamp,

@@ -62,6 +62,29 @@ def config_cases(index):
         print(key, index["cases"][key]["sha256"][:16], flush=True)
 
 
+PLANE_CASES = [   # key, width, height, max_depth, spp, seed, keep the frame
+    ("planes_phong@160x120_d0_s1", 160, 120, 0, 1, 0, True),
+    ("planes_phong@160x120_d3_s2", 160, 120, 3, 2, 21, True),
+    ("planes_phong@640x480_d5_s1", 640, 480, 5, 1, 0, False),
+]
+
+
+def plane_cases(index):
+    sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd", "py"))
+    from ptr_amd import synthetic as syn          # scene data only
+    soa, planes, phong = syn.planes_scene()
+    for key, w, h, depth, spp, seed, keep in PLANE_CASES:
+        out = orc.render_ext2(soa, syn.BACKGROUND, w, h, planes=planes, phong=phong, max_depth=depth, spp=spp, seed=seed, threads=8)
+        entry = dict(scene="synthetic.planes_scene", width=w, height=h, max_depth=depth, spp=spp, seed=seed,
+                     sha256=hashlib.sha256(out.tobytes()).hexdigest())
+        if keep:
+            rel = f"ext/{key}.rgba"
+            out.tofile(os.path.join(GOLDEN, rel))
+            entry["file"] = rel
+        index["cases"][key] = entry
+        print(key, entry["sha256"][:16], flush=True)
+
+
 def main():
     scenes = orc.load_scenes(GOLDEN)
     index = {"note": "outputs of oracle/ptr_oracle.c orc_render_ext (the extension-mode specification); "
@@ -81,6 +104,7 @@ def main():
         index["cases"][key] = entry
         print(key, entry["sha256"][:16])
     config_cases(index)
+    plane_cases(index)
     with open(os.path.join(GOLDEN, "ext", "index.json"), "w") as f:
         json.dump(index, f, indent=1)
 

@@ -207,6 +207,29 @@ def pack(rgb):
 
 
 # ---- extension modes (spec only; parity unpinned by the reference) ----------------------------
+class ExtExtra(C.Structure):
+    _fields_ = [("planes", C.POINTER(C.c_double)), ("n_planes", C.c_int), ("phong", C.POINTER(C.c_double))]
+
+
+def render_ext2(soa, bg, width, height, planes=None, phong=None, start_y=0, scan_height=None, max_depth=0, spp=1, seed=0, threads=8):
+    """the extension specification with planes ((14, n_planes)) and Phong terms ((2, n + n_planes): ks, exponent)"""
+    if scan_height is None:
+        scan_height = height
+    soa = np.ascontiguousarray(soa, dtype=np.float64)
+    bg = np.ascontiguousarray(bg, dtype=np.float64)
+    pl = np.ascontiguousarray(planes, dtype=np.float64) if planes is not None else np.zeros((14, 0))
+    ph = np.ascontiguousarray(phong, dtype=np.float64) if phong is not None else None
+    x = ExtExtra(_dp(pl), pl.shape[1], _dp(ph) if ph is not None else None)
+    out = np.empty(width * scan_height, dtype=np.uint32)
+    L = lib()
+    L.orc_render_ext2.argtypes = [C.POINTER(C.c_double), C.c_int, C.POINTER(ExtExtra), C.POINTER(C.c_double)] + [C.c_int] * 6 + \
+                                 [C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.c_int]
+    L.orc_render_ext2.restype = None
+    L.orc_render_ext2(_dp(soa), soa.shape[1], C.byref(x), _dp(bg), width, height, start_y, scan_height, max_depth, spp, seed,
+                      out.ctypes.data_as(C.POINTER(C.c_uint32)), None, threads)
+    return out
+
+
 def render_ext(soa, bg, width, height, start_y=0, scan_height=None, max_depth=0, spp=1, seed=0,
                want_rgb64=False, threads=8):
     if scan_height is None:

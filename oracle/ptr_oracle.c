@@ -305,8 +305,26 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 
 typedef struct { double o[3], d[3], w[3]; int depth; } ext_ray;
 
-/* nearest hit + hit frame shared by every node of the expansion (same arithmetic as orc_trace) */
-static int ext_nearest(const double *soa, int n, const double o[3], const double d[3], double *tnear_out, orc_counters *cnt)
+/* planes and Phong terms (include/ptr.h, "planes and Phong"): plane k's values are XP(row)[k], rows
+ * px py pz nx ny nz sr sg sb refl transp er eg eb; phong = ks[n + n_planes] then exponent[n + n_planes] */
+#define XP(k) (x->planes + (size_t)(k) * (size_t)x->n_planes)
+
+/* Plane.intersect of the specification: denom = d.n; 0 -> miss; t = ((p - o).n) / denom; t < 0 -> miss */
+static int plane_intersect(const orc_ext_extra *x, int k, const double o[3], const double d[3], double *t0, orc_counters *cnt)
+{
+    const double nx = XP(3)[k], ny = XP(4)[k], nz = XP(5)[k];
+    const double denom = d[0] * nx + d[1] * ny + d[2] * nz;
+    if (denom == 0) { if (cnt) cnt->exit_tca++; return 0; }
+    const double t = ((XP(0)[k] - o[0]) * nx + (XP(1)[k] - o[1]) * ny + (XP(2)[k] - o[2]) * nz) / denom;
+    if (t < 0) { if (cnt) cnt->exit_tca++; return 0; }
+    if (cnt) cnt->exit_hit++;
+    *t0 = t;
+    return 1;
+}
+
+/* nearest hit + hit frame shared by every node of the expansion (same arithmetic as orc_trace); spheres, then planes */
+static int ext_nearest(const double *soa, int n, const orc_ext_extra *x, const double o[3], const double d[3], double *tnear_out,
+                       orc_counters *cnt)
 {
     const double *cx = PL(0), *cy = PL(1), *cz = PL(2), *rad = PL(3);
     double tnear = ORC_INFINITY;
@@ -318,27 +336,56 @@ static int ext_nearest(const double *soa, int n, const double o[3], const double
             if (t0 < tnear) { tnear = t0; element = i; }
         }
     }
+    for (int k = 0; x && k < x->n_planes; k++) {
+        double t0 = ORC_INFINITY;
+        if (plane_intersect(x, k, o, d, &t0, cnt) && t0 < tnear) { tnear = t0; element = n + k; }
+    }
     *tnear_out = tnear;
     return element;
 }
 
-static void trace_ext_counted(const double *soa, int n, const double bg[3],
+static void trace_ext_counted(const double *soa, int n, const orc_ext_extra *x, const double bg[3],
                               const double o[3], const double d[3], int max_depth, double rgb[3],
                               orc_counters *cnt, uint64_t *secondary);
 
 void orc_trace_ext(const double *soa, int n, const double bg[3],
                    const double o[3], const double d[3], int max_depth, double rgb[3])
 {
-    trace_ext_counted(soa, n, bg, o, d, max_depth, rgb, 0, 0);
+    trace_ext_counted(soa, n, 0, bg, o, d, max_depth, rgb, 0, 0);
 }
 
-static void trace_ext_counted(const double *soa, int n, const double bg[3],
+void orc_trace_ext2(const double *soa, int n, const orc_ext_extra *x, const double bg[3],
+                    const double o[3], const double d[3], int max_depth, double rgb[3])
+{
+    trace_ext_counted(soa, n, x, bg, o, d, max_depth, rgb, 0, 0);
+}
+
+/* the material / position values of element e (a sphere, or plane e - n) */
+typedef struct { double c[3], sc[3], em[3], refl, transp; } ext_elem;
+static ext_elem ext_element(const double *soa, int n, const orc_ext_extra *x, int e)
+{
+    ext_elem m;
+    if (e < n) {
+        m.c[0] = PL(0)[e]; m.c[1] = PL(1)[e]; m.c[2] = PL(2)[e];
+        m.sc[0] = PL(4)[e]; m.sc[1] = PL(5)[e]; m.sc[2] = PL(6)[e];
+        m.refl = PL(7)[e]; m.transp = PL(8)[e];
+        m.em[0] = PL(9)[e]; m.em[1] = PL(10)[e]; m.em[2] = PL(11)[e];
+    } else {
+        const int k = e - n;
+        m.c[0] = XP(0)[k]; m.c[1] = XP(1)[k]; m.c[2] = XP(2)[k];
+        m.sc[0] = XP(6)[k]; m.sc[1] = XP(7)[k]; m.sc[2] = XP(8)[k];
+        m.refl = XP(9)[k]; m.transp = XP(10)[k];
+        m.em[0] = XP(11)[k]; m.em[1] = XP(12)[k]; m.em[2] = XP(13)[k];
+    }
+    return m;
+}
+
+static void trace_ext_counted(const double *soa, int n, const orc_ext_extra *x, const double bg[3],
                               const double o[3], const double d[3], int max_depth, double rgb[3],
                               orc_counters *cnt, uint64_t *secondary)
 {
     const double *cx = PL(0), *cy = PL(1), *cz = PL(2), *rad = PL(3);
-    const double *sr = PL(4), *sg = PL(5), *sb = PL(6), *refl = PL(7), *transp = PL(8);
-    const double *er = PL(9), *eg = PL(10), *eb = PL(11);
+    const int np = x ? x->n_planes : 0, ne = n + np;
     if (max_depth > ORC_MAX_DEPTH) max_depth = ORC_MAX_DEPTH;
     ext_ray stack[ORC_MAX_DEPTH + 2];
     int top = 0;
@@ -349,25 +396,33 @@ static void trace_ext_counted(const double *soa, int n, const double bg[3],
     while (top > 0) {
         const ext_ray r = stack[--top];
         double tnear;
-        const int e = ext_nearest(soa, n, r.o, r.d, &tnear, cnt);
+        const int e = ext_nearest(soa, n, x, r.o, r.d, &tnear, cnt);
         if (e < 0) {
             acc[0] += r.w[0] * bg[0]; acc[1] += r.w[1] * bg[1]; acc[2] += r.w[2] * bg[2];
             continue;
         }
         if (cnt) cnt->hits++;
-        acc[0] += r.w[0] * er[e]; acc[1] += r.w[1] * eg[e]; acc[2] += r.w[2] * eb[e];
+        const ext_elem me = ext_element(soa, n, x, e);
+        const double *er = 0, *eg = 0, *eb = 0; (void)er; (void)eg; (void)eb;
+        const double sr_e = me.sc[0], sg_e = me.sc[1], sb_e = me.sc[2], refl_e = me.refl, transp_e = me.transp;
+        acc[0] += r.w[0] * me.em[0]; acc[1] += r.w[1] * me.em[1]; acc[2] += r.w[2] * me.em[2];
         double P[3] = { r.o[0] + r.d[0] * tnear, r.o[1] + r.d[1] * tnear, r.o[2] + r.d[2] * tnear };
-        double N[3] = { P[0] - cx[e], P[1] - cy[e], P[2] - cz[e] };
-        v_normalize(N);
+        double N[3];
+        if (e < n) {
+            N[0] = P[0] - cx[e]; N[1] = P[1] - cy[e]; N[2] = P[2] - cz[e];
+            v_normalize(N);
+        } else {                       /* a plane's normal is the unit vector it was given */
+            N[0] = XP(3)[e - n]; N[1] = XP(4)[e - n]; N[2] = XP(5)[e - n];
+        }
         int inside = 0;
         double dn = r.d[0] * N[0] + r.d[1] * N[1] + r.d[2] * N[2];
         if (dn > 0) { N[0] = -N[0]; N[1] = -N[1]; N[2] = -N[2]; inside = 1; dn = -dn; }
-        if ((transp[e] > 0 || refl[e] > 0) && r.depth < max_depth) {
+        if ((transp_e > 0 || refl_e > 0) && r.depth < max_depth) {
             const double facing = -dn;
             const double f = 1 - facing;
             const double fresnel = 1 * 0.1 + (f * f * f) * (1 - 0.1);
-            const double wsc[3] = { r.w[0] * sr[e], r.w[1] * sg[e], r.w[2] * sb[e] };
-            if (transp[e] > 0) {
+            const double wsc[3] = { r.w[0] * sr_e, r.w[1] * sg_e, r.w[2] * sb_e };
+            if (transp_e > 0) {
                 const double eta = inside ? 1.1 : 1 / 1.1;
                 const double cosi = -dn;
                 const double k = 1 - eta * eta * (1 - cosi * cosi);
@@ -375,7 +430,7 @@ static void trace_ext_counted(const double *soa, int n, const double bg[3],
                     ext_ray *c = &stack[top++];
                     if (secondary) (*secondary)++;
                     const double g = eta * cosi - sqrt(k);
-                    const double wt = (1 - fresnel) * transp[e];
+                    const double wt = (1 - fresnel) * transp_e;
                     for (int a = 0; a < 3; a++) {
                         c->o[a] = P[a] - N[a] * ORC_BIAS;
                         c->d[a] = r.d[a] * eta + N[a] * g;
@@ -396,25 +451,40 @@ static void trace_ext_counted(const double *soa, int n, const double bg[3],
             v_normalize(c->d);
             c->depth = r.depth + 1;
         } else {
-            /* the reference's direct lighting (RayTracer.js:60-91) */
+            /* the reference's direct lighting (RayTracer.js:60-91), over spheres and planes, with the Phong term */
             double dif[3] = { 0, 0, 0 };
-            for (int i = 0; i < n; i++) {
-                if (er[i] > 0 || eg[i] > 0 || eb[i] > 0) {
+            const double ks = (x && x->phong) ? x->phong[e] : 0.0;
+            const double two_dn = 2 * dn;
+            const double Rv[3] = { r.d[0] - N[0] * two_dn, r.d[1] - N[1] * two_dn, r.d[2] - N[2] * two_dn };
+            for (int i = 0; i < ne; i++) {
+                const ext_elem li = ext_element(soa, n, x, i);
+                if (li.em[0] > 0 || li.em[1] > 0 || li.em[2] > 0) {
                     double tr = 1.0;
-                    double L[3] = { cx[i] - P[0], cy[i] - P[1], cz[i] - P[2] };
+                    double L[3] = { li.c[0] - P[0], li.c[1] - P[1], li.c[2] - P[2] };
+                    const double len2 = L[0] * L[0] + L[1] * L[1] + L[2] * L[2];     /* a plane only blocks in front of the light */
                     v_normalize(L);
                     if (cnt) cnt->shadow_rays++;
-                    for (int j = 0; j < n; j++) {
+                    for (int j = 0; j < ne; j++) {
                         if (i != j) {
                             double so[3] = { P[0] + N[0] * ORC_BIAS, P[1] + N[1] * ORC_BIAS, P[2] + N[2] * ORC_BIAS };
                             double t0, t1;
-                            if (intersect_r2(so, L, cx[j], cy[j], cz[j], rad[j] * rad[j], &t0, &t1, cnt)) { tr = 0.0; break; }
+                            if (j < n ? intersect_r2(so, L, cx[j], cy[j], cz[j], rad[j] * rad[j], &t0, &t1, cnt)
+                                      : (plane_intersect(x, j - n, so, L, &t0, cnt) && t0 * t0 < len2)) { tr = 0.0; break; }
                         }
                     }
                     double ratio = js_max0(N[0] * L[0] + N[1] * L[1] + N[2] * L[2]);
-                    dif[0] += (sr[e] * tr) * (er[i] * ratio);
-                    dif[1] += (sg[e] * tr) * (eg[i] * ratio);
-                    dif[2] += (sb[e] * tr) * (eb[i] * ratio);
+                    dif[0] += (sr_e * tr) * (li.em[0] * ratio);
+                    dif[1] += (sg_e * tr) * (li.em[1] * ratio);
+                    dif[2] += (sb_e * tr) * (li.em[2] * ratio);
+                    if (ks > 0) {
+                        const double sp = js_max0(Rv[0] * L[0] + Rv[1] * L[1] + Rv[2] * L[2]);
+                        double ph = 1.0, b = sp;
+                        for (unsigned q = (unsigned)x->phong[ne + e]; q > 0; q >>= 1) { if (q & 1u) ph = ph * b; b = b * b; }
+                        const double kp = ks * ph;
+                        dif[0] += tr * (li.em[0] * kp);
+                        dif[1] += tr * (li.em[1] * kp);
+                        dif[2] += tr * (li.em[2] * kp);
+                    }
                 }
             }
             acc[0] += r.w[0] * dif[0]; acc[1] += r.w[1] * dif[1]; acc[2] += r.w[2] * dif[2];
@@ -427,6 +497,7 @@ typedef struct {
     const double *soa; int n; const double *bg; int width, height, start_y, scan_height;
     int max_depth, spp; uint32_t seed; uint32_t *out8; double *out64; int first, step;
     orc_counters *cnt; uint64_t *secondary;          /* single-threaded callers only */
+    const orc_ext_extra *x;
 } ext_job;
 
 static void *ext_main(void *p)
@@ -452,7 +523,7 @@ static void *ext_main(void *p)
                 v_normalize(dir);
                 double c[3];
                 if (j->cnt) j->cnt->primary++;
-                trace_ext_counted(j->soa, j->n, j->bg, origin, dir, j->max_depth, c, j->cnt, j->secondary);
+                trace_ext_counted(j->soa, j->n, j->x, j->bg, origin, dir, j->max_depth, c, j->cnt, j->secondary);
                 sum[0] += c[0]; sum[1] += c[1]; sum[2] += c[2];
             }
             if (j->spp > 1) { sum[0] /= j->spp; sum[1] /= j->spp; sum[2] /= j->spp; }
@@ -468,12 +539,20 @@ void orc_render_ext(const double *soa, int n, const double bg[3],
                     int max_depth, int spp, uint32_t seed,
                     uint32_t *out_rgba8, double *out_rgb64, int nthreads)
 {
+    orc_render_ext2(soa, n, 0, bg, width, height, start_y, scan_height, max_depth, spp, seed, out_rgba8, out_rgb64, nthreads);
+}
+
+void orc_render_ext2(const double *soa, int n, const orc_ext_extra *x, const double bg[3],
+                     int width, int height, int start_y, int scan_height,
+                     int max_depth, int spp, uint32_t seed,
+                     uint32_t *out_rgba8, double *out_rgb64, int nthreads)
+{
     if (nthreads < 1) nthreads = 1;
     if (spp < 1) spp = 1;
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
     ext_job *jobs = (ext_job *)malloc(sizeof(ext_job) * (size_t)nthreads);
     for (int t = 0; t < nthreads; t++) {
-        ext_job j = { soa, n, bg, width, height, start_y, scan_height, max_depth, spp, seed, out_rgba8, out_rgb64, t, nthreads, 0, 0 };
+        ext_job j = { soa, n, bg, width, height, start_y, scan_height, max_depth, spp, seed, out_rgba8, out_rgb64, t, nthreads, 0, 0, x };
         jobs[t] = j;
         pthread_create(&th[t], 0, ext_main, &jobs[t]);
     }
@@ -485,9 +564,16 @@ void orc_count_ext(const double *soa, int n, const double bg[3],
                    int width, int height, int start_y, int scan_height,
                    int max_depth, int spp, uint32_t seed, orc_counters *cnt, uint64_t *secondary)
 {
+    orc_count_ext2(soa, n, 0, bg, width, height, start_y, scan_height, max_depth, spp, seed, cnt, secondary);
+}
+
+void orc_count_ext2(const double *soa, int n, const orc_ext_extra *x, const double bg[3],
+                    int width, int height, int start_y, int scan_height,
+                    int max_depth, int spp, uint32_t seed, orc_counters *cnt, uint64_t *secondary)
+{
     memset(cnt, 0, sizeof *cnt);
     *secondary = 0;
-    ext_job j = { soa, n, bg, width, height, start_y, scan_height, max_depth, spp < 1 ? 1 : spp, seed, 0, 0, 0, 1, cnt, secondary };
+    ext_job j = { soa, n, bg, width, height, start_y, scan_height, max_depth, spp < 1 ? 1 : spp, seed, 0, 0, 0, 1, cnt, secondary, x };
     ext_main(&j);
 }
 

@@ -62,6 +62,9 @@ struct ptr_ctx {
     double bg[3] = {0, 0, 0};
     ptr_camera cam;
     bool cam_general = false;
+    // extension scene data (ptr_set_extension_f64): planes (14 rows of n_planes), Phong terms (ks, exponent per element)
+    std::vector<double> planes, phong;
+    int n_planes = 0, n_phong = 0;     // n_phong: elements the Phong arrays were given for (0 = none)
     bool dirty = true;                 // frame blocks need a rebuild + upload
     bool needs_exact = false;          // some frame holds values the float32 path cannot take
 
@@ -136,10 +139,11 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct BlockLayout {
     uint32_t off_g64, off_m64, off_p32, off_m32, off_lights, off_pairs, off_lrec, off_cull;
+    uint32_t off_pl64, off_plm64, off_pl32, off_plm32, off_ph64, off_ph32;
     size_t   bytes;
 };
 
-BlockLayout block_layout(int n)
+BlockLayout block_layout(int n, int np = 0, bool phong = false)
 {
     BlockLayout L;
     size_t o = sizeof(FrameHeader);
@@ -159,6 +163,15 @@ BlockLayout block_layout(int n)
     L.off_lrec = (uint32_t)o;   o += sizeof(LightRec) * ((size_t)n + 1);
     o = align_up(o, 64);
     L.off_cull = (uint32_t)o;   o += sizeof(CullRec) * ((size_t)n + 1);
+    // planes and Phong terms (extension modes; empty otherwise)
+    o = align_up(o, 64);
+    L.off_pl64 = (uint32_t)o;   o += sizeof(PlaneG64) * (size_t)np;
+    L.off_plm64 = (uint32_t)o;  o += sizeof(SphereM64) * (size_t)np;
+    L.off_pl32 = (uint32_t)o;   o += sizeof(PlaneP32) * (size_t)np;
+    L.off_plm32 = (uint32_t)o;  o += sizeof(SphereM32) * (size_t)np;
+    o = align_up(o, 16);
+    L.off_ph64 = (uint32_t)o;   o += phong ? sizeof(double) * 2 * ((size_t)n + (size_t)np) : 0;
+    L.off_ph32 = (uint32_t)o;   o += phong ? sizeof(float) * 2 * ((size_t)n + (size_t)np) : 0;
     L.bytes = align_up(o, 256);
     return L;
 }
@@ -170,7 +183,8 @@ constexpr double PR_RELB = 10.0 * EPS32;   // b = l.d:          |err| <= PR_RELB
 
 // Flatten one scene (12 planes of n doubles) into a frame block.  Returns needs_exact.
 bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* soa, int n,
-                       const double bg[3], const double org[3])
+                       const double bg[3], const double org[3],
+                       const double* planes = nullptr, int np = 0, const double* phong = nullptr)
 {
     std::memset(dst, 0, L.bytes);
     FrameHeader* h = reinterpret_cast<FrameHeader*>(dst);
@@ -291,6 +305,28 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
     h->self_skip = self_skip ? 1u : 0u;
     h->off_g64 = L.off_g64; h->off_m64 = L.off_m64; h->off_p32 = L.off_p32;
     h->off_m32 = L.off_m32; h->off_lights = L.off_lights;
+    h->n_planes = (uint32_t)np; h->has_phong = phong ? 1u : 0u;
+    h->off_pl64 = L.off_pl64; h->off_plm64 = L.off_plm64; h->off_pl32 = L.off_pl32; h->off_plm32 = L.off_plm32;
+    h->off_ph64 = L.off_ph64; h->off_ph32 = L.off_ph32;
+    {
+        PlaneG64* g = reinterpret_cast<PlaneG64*>(dst + L.off_pl64);
+        SphereM64* m = reinterpret_cast<SphereM64*>(dst + L.off_plm64);
+        PlaneP32* g32 = reinterpret_cast<PlaneP32*>(dst + L.off_pl32);
+        SphereM32* mm = reinterpret_cast<SphereM32*>(dst + L.off_plm32);
+        auto xp = [&](int row, int k) { return planes[(size_t)row * (size_t)np + (size_t)k]; };
+        for (int k = 0; k < np; k++) {
+            g[k] = PlaneG64{xp(0, k), xp(1, k), xp(2, k), xp(3, k), xp(4, k), xp(5, k)};
+            m[k] = SphereM64{xp(6, k), xp(7, k), xp(8, k), xp(11, k), xp(12, k), xp(13, k), xp(9, k), xp(10, k)};
+            g32[k] = PlaneP32{(float)(xp(0, k) - org[0]), (float)(xp(1, k) - org[1]), (float)(xp(2, k) - org[2]), (float)xp(9, k),
+                              (float)xp(3, k), (float)xp(4, k), (float)xp(5, k), (float)xp(10, k)};
+            mm[k] = SphereM32{(float)xp(6, k), (float)xp(7, k), (float)xp(8, k), 0.0f, (float)xp(11, k), (float)xp(12, k), (float)xp(13, k), 0.0f};
+        }
+        if (phong) {
+            double* p64 = reinterpret_cast<double*>(dst + L.off_ph64);
+            float* p32f = reinterpret_cast<float*>(dst + L.off_ph32);
+            for (int k = 0; k < 2 * (n + np); k++) { p64[k] = phong[k]; p32f[k] = (float)phong[k]; }
+        }
+    }
     return needs_exact;
 }
 
@@ -316,7 +352,11 @@ int mark_launch(ptr_ctx* c, hipStream_t s)
 int ensure_uploaded(ptr_ctx* c, hipStream_t s)
 {
     if (!c->dirty) return PTR_OK;
-    const BlockLayout L = block_layout(c->n_spheres);
+    const bool phong = c->n_phong > 0;
+    if (phong && c->n_phong != c->n_spheres + c->n_planes)
+        return fail(c, PTR_ERR_INVALID, "the Phong terms were given for %d elements, the scene has %d spheres + %d planes "
+                                        "(ptr_set_extension_f64 after ptr_set_scene*)", c->n_phong, c->n_spheres, c->n_planes);
+    const BlockLayout L = block_layout(c->n_spheres, c->n_planes, phong);
     try {
         c->host_blocks.resize(L.bytes * (size_t)c->n_frames);
     } catch (const std::bad_alloc&) {
@@ -326,7 +366,7 @@ int ensure_uploaded(ptr_ctx* c, hipStream_t s)
     for (int f = 0; f < c->n_frames; f++)
         ne |= build_frame_block(c->host_blocks.data() + L.bytes * (size_t)f, L,
                                 c->soa.data() + (size_t)f * 12u * (size_t)c->n_spheres, c->n_spheres,
-                                c->bg, c->cam.origin);
+                                c->bg, c->cam.origin, c->planes.data(), c->n_planes, phong ? c->phong.data() : nullptr);
     PTR_TRY(order_after_last(c, s));
     PTR_TRY(grow(c, c->scenes, c->host_blocks.size()));          // (a hipFree waits for the whole device)
     HIP_TRY(c, hipMemcpyAsync(c->scenes.ptr, c->host_blocks.data(), c->host_blocks.size(),
@@ -363,12 +403,13 @@ int check_params(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frames)
     if (p->max_depth < 0 || p->max_depth > PTR_MAX_DEPTH_LIMIT || p->spp < 1 || p->spp > PTR_MAX_SPP)
         return fail(c, PTR_ERR_INVALID, "max_depth must be in [0, %d] and spp in [1, %d] (got %d, %d)",
                     PTR_MAX_DEPTH_LIMIT, PTR_MAX_SPP, p->max_depth, p->spp);
-    if (p->max_depth != 0 || p->spp != 1) {
+    if (p->max_depth != 0 || p->spp != 1 || c->n_planes > 0 || c->n_phong > 0) {
         // extension modes (ptr_kernels_ext.hip): not reference behaviour, so no reference quirk and no
         // reference work counters exist for them
         if (p->flags & PTR_QUIRK_ROW_SHIFT)
             return fail(c, PTR_ERR_INVALID, "PTR_QUIRK_ROW_SHIFT applies to the reference semantics only "
-                                            "(max_depth 0, spp 1); got max_depth=%d spp=%d", p->max_depth, p->spp);
+                                            "(max_depth 0, spp 1, no planes, no Phong terms); got max_depth=%d spp=%d planes=%d",
+                        p->max_depth, p->spp, c->n_planes);
     }
     if ((p->flags & PTR_MODE_EXACT_F64) && (p->flags & PTR_MODE_F32_ONLY))
         return fail(c, PTR_ERR_INVALID, "PTR_MODE_EXACT_F64 and PTR_MODE_F32_ONLY are exclusive");
@@ -484,8 +525,8 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
         HIP_TRY(c, hipEventRecord(c->ev[0], s));
     }
 
-    if (p->max_depth != 0 || p->spp != 1) {
-        // Extension modes: float64 = the specification bit for bit, and that is the DEFAULT: a float32 ray tree has no
+    if (p->max_depth != 0 || p->spp != 1 || c->n_planes > 0 || c->n_phong > 0) {
+        // Extension modes (bounces, samples, planes, Phong terms): float64 = the specification bit for bit, and that is the DEFAULT: a float32 ray tree has no
         // error bounds yet that would tell which pixels to re-do (errors grow with every bounce off a curved surface), and
         // the contract is <= 1/255 on every pixel.  PTR_MODE_F32_ONLY asks for the float32 throughput form explicitly.
         a.max_depth = p->max_depth; a.spp = p->spp; a.seed = p->seed;
@@ -708,6 +749,36 @@ int ptr_set_camera(ptr_ctx* c, const ptr_camera* cam)
     return PTR_OK;
 }
 
+int ptr_set_extension_f64(ptr_ctx* c, const double* planes_soa, int n_planes, const double* phong, int n_elements)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (n_planes < 0 || n_planes > 4096 || (n_planes > 0 && !planes_soa)) return fail(c, PTR_ERR_INVALID, "bad plane list (%d planes)", n_planes);
+    if (phong && n_elements < 1) return fail(c, PTR_ERR_INVALID, "Phong terms need n_elements >= 1");
+    for (int k = 0; k < n_planes; k++) {
+        const double nx = planes_soa[3 * (size_t)n_planes + k], ny = planes_soa[4 * (size_t)n_planes + k], nz = planes_soa[5 * (size_t)n_planes + k];
+        if (!(std::fabs(nx * nx + ny * ny + nz * nz - 1.0) <= 1e-9))
+            return fail(c, PTR_ERR_INVALID, "plane %d: the normal must be a unit vector", k);
+        for (int row = 0; row < 14; row++)
+            if (!(std::fabs(planes_soa[(size_t)row * (size_t)n_planes + k]) <= 1e15)) return fail(c, PTR_ERR_INVALID, "plane %d: value %d is not finite", k, row);
+    }
+    for (int k = 0; phong && k < n_elements; k++) {
+        const double ks = phong[k], m = phong[(size_t)n_elements + k];
+        if (!(ks >= 0 && ks <= 1e15) || !(m >= 1 && m <= 65536 && m == std::floor(m)))
+            return fail(c, PTR_ERR_INVALID, "element %d: ks must be >= 0 and the exponent an integer in 1..65536 (got %g, %g)", k, ks, m);
+    }
+    try {
+        c->planes.assign(planes_soa, planes_soa + (size_t)14 * (size_t)n_planes);
+        if (phong) c->phong.assign(phong, phong + 2 * (size_t)n_elements); else c->phong.clear();
+    } catch (const std::bad_alloc&) {
+        return fail(c, PTR_ERR_INVALID, "out of host memory");
+    }
+    c->n_planes = n_planes;
+    c->n_phong = phong ? n_elements : 0;
+    c->dirty = true;
+    return PTR_OK;
+}
+
 int ptr_render_device(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frames,
                       void* d_rgba8, void* d_rgba32f, void* stream)
 {
@@ -820,6 +891,9 @@ static int trace_batch_locked(ptr_ctx* c, const double* origins, const double or
                               double* out_rgb, int32_t* out_element, double* out_hit, double* out_normal, bool rc)
 {
     if (!c->have_scene) return fail(c, PTR_ERR_NO_SCENE, "no scene uploaded (call ptr_set_scene* first)");
+    if (c->n_planes > 0 || c->n_phong > 0)
+        return fail(c, PTR_ERR_UNSUPPORTED, "the single-ray entries have the reference's semantics (spheres, Lambert): clear the planes / "
+                                            "Phong terms (ptr_set_extension_f64(ctx, NULL, 0, NULL, 0)) first");
     if (n < 0) return fail(c, PTR_ERR_INVALID, "n < 0");
     if (n == 0) return PTR_OK;
     if (!dirs || !out_rgb) return fail(c, PTR_ERR_INVALID, "dirs_xyz / out_rgb64 is NULL");

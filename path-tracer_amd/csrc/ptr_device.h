@@ -43,7 +43,11 @@ struct alignas(16) FrameHeader {          // 128 bytes
     float    pad0;
     uint32_t off_g64, off_m64, off_p32, off_m32, off_lights, off_pad;   // byte offsets in block
     uint32_t self_skip;                   // 1: coordinates are small enough for the "own sphere never shadows" proof
-    uint32_t pad1[9];
+    // planes and Phong terms (extension modes only, include/ptr.h "planes and Phong"); elements = spheres, then planes
+    uint32_t n_planes;
+    uint32_t has_phong;                   // 1: phong64 / phong32 hold ks[n + n_planes] then exponent[n + n_planes]
+    uint32_t off_pl64, off_plm64, off_pl32, off_plm32, off_ph64, off_ph32;
+    uint32_t pad1[1];
 };
 static_assert(sizeof(FrameHeader) == 128, "FrameHeader layout");
 
@@ -78,6 +82,11 @@ static_assert(sizeof(SphereP32) == 64, "SphereP32 layout");
 // material, gathered per lane for the winning sphere; scmax/emax = largest channel
 struct alignas(16) SphereM32 { float sr, sg, sb, scmax, er, eg, eb, emax; };
 
+// planes (extension modes): point p, unit normal n; the float32 record is relative to the camera origin like SphereP32
+struct alignas(16) PlaneG64 { double px, py, pz, nx, ny, nz; };
+struct alignas(16) PlaneP32 { float px, py, pz, refl, nx, ny, nz, transp; };
+static_assert(sizeof(PlaneG64) == 48 && sizeof(PlaneP32) == 32, "plane record layout");
+
 // Shadow pre-filter, one record per (light k, element j), laid out [k][pair_stride(n)] (rows padded with
 // never-cull records to a multiple of 4 records, so a row can be read 16 floats at a time):
 // a = unit vector from the light's centre to element j's centre, thr = lower bound of |L.a| for
@@ -103,6 +112,13 @@ struct FrameView {
     const SphereP32* p32;
     const SphereM32* m32;
     const int32_t*   lights;
+    // planes / Phong (read through the header's offsets by the extension kernels only)
+    __host__ __device__ const PlaneG64* pl64() const { return reinterpret_cast<const PlaneG64*>(reinterpret_cast<const unsigned char*>(h) + h->off_pl64); }
+    __host__ __device__ const SphereM64* plm64() const { return reinterpret_cast<const SphereM64*>(reinterpret_cast<const unsigned char*>(h) + h->off_plm64); }
+    __host__ __device__ const PlaneP32* pl32() const { return reinterpret_cast<const PlaneP32*>(reinterpret_cast<const unsigned char*>(h) + h->off_pl32); }
+    __host__ __device__ const SphereM32* plm32() const { return reinterpret_cast<const SphereM32*>(reinterpret_cast<const unsigned char*>(h) + h->off_plm32); }
+    __host__ __device__ const double* ph64() const { return reinterpret_cast<const double*>(reinterpret_cast<const unsigned char*>(h) + h->off_ph64); }
+    __host__ __device__ const float* ph32() const { return reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(h) + h->off_ph32); }
 };
 
 __host__ __device__ inline FrameView frame_view(const unsigned char* block)

@@ -42,6 +42,15 @@ template <> struct SceneT<double> {
     __device__ double refl(int i) const { return fv.m64[i].refl; }
     __device__ double transp(int i) const { return fv.m64[i].transp; }
     __device__ V<double> bg() const { return V<double>{fv.h->bg64[0], fv.h->bg64[1], fv.h->bg64[2]}; }
+    // planes (element n + k) and Phong terms
+    __device__ V<double> pl_p(int k) const { const PlaneG64& g = fv.pl64()[k]; return V<double>{g.px, g.py, g.pz}; }
+    __device__ V<double> pl_n(int k) const { const PlaneG64& g = fv.pl64()[k]; return V<double>{g.nx, g.ny, g.nz}; }
+    __device__ V<double> pl_sc(int k) const { const SphereM64& m = fv.plm64()[k]; return V<double>{m.sr, m.sg, m.sb}; }
+    __device__ V<double> pl_em(int k) const { const SphereM64& m = fv.plm64()[k]; return V<double>{m.er, m.eg, m.eb}; }
+    __device__ double pl_refl(int k) const { return fv.plm64()[k].refl; }
+    __device__ double pl_transp(int k) const { return fv.plm64()[k].transp; }
+    __device__ double ks(int e) const { return fv.ph64()[e]; }
+    __device__ unsigned phong_exp(int e, int ne) const { return (unsigned)fv.ph64()[ne + e]; }
 };
 template <> struct SceneT<float> {
     FrameView fv;
@@ -52,6 +61,14 @@ template <> struct SceneT<float> {
     __device__ float refl(int i) const { return fv.p32[i].refl; }
     __device__ float transp(int i) const { return fv.p32[i].transp; }
     __device__ V<float> bg() const { return V<float>{fv.h->bg32[0], fv.h->bg32[1], fv.h->bg32[2]}; }
+    __device__ V<float> pl_p(int k) const { const PlaneP32& g = fv.pl32()[k]; return V<float>{g.px, g.py, g.pz}; }
+    __device__ V<float> pl_n(int k) const { const PlaneP32& g = fv.pl32()[k]; return V<float>{g.nx, g.ny, g.nz}; }
+    __device__ V<float> pl_sc(int k) const { const SphereM32& m = fv.plm32()[k]; return V<float>{m.sr, m.sg, m.sb}; }
+    __device__ V<float> pl_em(int k) const { const SphereM32& m = fv.plm32()[k]; return V<float>{m.er, m.eg, m.eb}; }
+    __device__ float pl_refl(int k) const { return fv.pl32()[k].refl; }
+    __device__ float pl_transp(int k) const { return fv.pl32()[k].transp; }
+    __device__ float ks(int e) const { return fv.ph32()[e]; }
+    __device__ unsigned phong_exp(int e, int ne) const { return (unsigned)fv.ph32()[ne + e]; }
 };
 
 // per-lane work counters (PTR_FLAG_STATS), same meaning as ptr_stats in include/ptr.h
@@ -76,6 +93,19 @@ __device__ __forceinline__ bool intersect_t(const V<T>& o, const V<T>& d, const 
     return true;
 }
 
+// Plane.intersect of the specification (include/ptr.h "planes and Phong"): denom = d.n; 0 -> miss; t = ((p - o).n) / denom
+template <typename T, bool STATS>
+__device__ __forceinline__ bool plane_t(const V<T>& o, const V<T>& d, const V<T>& p, const V<T>& n, T& t0, ExtCounts* k)
+{
+    const T denom = d.x * n.x + d.y * n.y + d.z * n.z;
+    if (denom == 0) { xcount<STATS>(k, XT_EXIT_TCA); return false; }
+    const T t = ((p.x - o.x) * n.x + (p.y - o.y) * n.y + (p.z - o.z) * n.z) / denom;
+    if (t < 0) { xcount<STATS>(k, XT_EXIT_TCA); return false; }
+    xcount<STATS>(k, XT_EXIT_HIT);
+    t0 = t;
+    return true;
+}
+
 template <typename T> struct ExtRay { V<T> o, d, w; int depth; };
 
 // weighted depth-first expansion (include/ptr.h, "extension modes")
@@ -83,6 +113,8 @@ template <typename T, bool STATS>
 __device__ V<T> trace_ext(const SceneT<T>& sc, V<T> o0, V<T> d0, int max_depth, ExtCounts* k)
 {
     const int n = sc.fv.h->n, nl = sc.fv.h->n_lights;
+    const int np = (int)sc.fv.h->n_planes, ne = n + np;            // elements = spheres, then planes
+    const bool phong = sc.fv.h->has_phong != 0u;
     // The ray that would be popped next stays in registers (a reflection is pushed last, so it is processed first):
     // same rays in the same order, and only a second child travels through the scratch-memory stack.
     ExtRay<T> stack[PTR_EXT_MAX_DEPTH + 2];
@@ -103,20 +135,31 @@ __device__ V<T> trace_ext(const SceneT<T>& sc, V<T> o0, V<T> d0, int max_depth, 
                 if (t0 < tnear) { tnear = t0; e = i; }
             }
         }
+        for (int q = 0; q < np; q++) {
+            T t0 = T(PTR_INFINITY);
+            if (plane_t<T, STATS>(r.o, r.d, sc.pl_p(q), sc.pl_n(q), t0, k) && t0 < tnear) { tnear = t0; e = n + q; }
+        }
         if (e < 0) {
             acc.x += r.w.x * bg.x; acc.y += r.w.y * bg.y; acc.z += r.w.z * bg.z;
             continue;
         }
         xcount<STATS>(k, XT_HITS);
-        const V<T> em = sc.em(e), col = sc.sc(e), C = sc.center(e);
+        const bool on_plane = e >= n;
+        const V<T> em = on_plane ? sc.pl_em(e - n) : sc.em(e), col = on_plane ? sc.pl_sc(e - n) : sc.sc(e);
         acc.x += r.w.x * em.x; acc.y += r.w.y * em.y; acc.z += r.w.z * em.z;
         const V<T> P{r.o.x + r.d.x * tnear, r.o.y + r.d.y * tnear, r.o.z + r.d.z * tnear};
-        V<T> N{P.x - C.x, P.y - C.y, P.z - C.z};
-        normalize_v(N);
+        V<T> N;
+        if (on_plane) {
+            N = sc.pl_n(e - n);                                   // a plane's normal is the unit vector it was given
+        } else {
+            const V<T> C = sc.center(e);
+            N = V<T>{P.x - C.x, P.y - C.y, P.z - C.z};
+            normalize_v(N);
+        }
         bool inside = false;
         T dn = r.d.x * N.x + r.d.y * N.y + r.d.z * N.z;
         if (dn > 0) { N.x = -N.x; N.y = -N.y; N.z = -N.z; inside = true; dn = -dn; }
-        const T transp = sc.transp(e), refl = sc.refl(e);
+        const T transp = on_plane ? sc.pl_transp(e - n) : sc.transp(e), refl = on_plane ? sc.pl_refl(e - n) : sc.refl(e);
         if ((transp > 0 || refl > 0) && r.depth < max_depth) {
             const T facing = -dn;
             const T f = 1 - facing;
@@ -149,26 +192,51 @@ __device__ V<T> trace_ext(const SceneT<T>& sc, V<T> o0, V<T> d0, int max_depth, 
             r = c;
             have = true;
         } else {
-            // the reference's direct lighting (RayTracer.js:60-91)
+            // the reference's direct lighting (RayTracer.js:60-91), over spheres and planes, with the Phong term
             const V<T> so{P.x + N.x * T(PTR_BIAS), P.y + N.y * T(PTR_BIAS), P.z + N.z * T(PTR_BIAS)};
             V<T> dif{0, 0, 0};
-            for (int kk = 0; kk < nl; kk++) {
-                const int i = sc.fv.lights[kk];
-                const V<T> Ci = sc.center(i), ei = sc.em(i);
+            const T ks = phong ? sc.ks(e) : T(0);
+            const T two_dn = 2 * dn;
+            const V<T> Rv{r.d.x - N.x * two_dn, r.d.y - N.y * two_dn, r.d.z - N.z * two_dn};
+            // lights: the emissive spheres in scene order (the host's list), then the emissive planes
+            for (int kk = 0; kk < nl + np; kk++) {
+                int i;
+                V<T> Ci, ei;
+                if (kk < nl) {
+                    i = sc.fv.lights[kk];
+                    Ci = sc.center(i); ei = sc.em(i);
+                } else {
+                    i = n + (kk - nl);
+                    ei = sc.pl_em(kk - nl);
+                    if (!(ei.x > 0 || ei.y > 0 || ei.z > 0)) continue;
+                    Ci = sc.pl_p(kk - nl);
+                }
                 V<T> L{Ci.x - P.x, Ci.y - P.y, Ci.z - P.z};
+                const T len2 = L.x * L.x + L.y * L.y + L.z * L.z;                    // a plane only blocks in front of the light
                 normalize_v(L);
                 xcount<STATS>(k, XT_SHADOW);
                 T tr = 1;
-                for (int j = 0; j < n; j++) {
+                for (int j = 0; j < ne; j++) {
                     if (j == i) continue;
                     T t0, t1;
-                    if (intersect_t<T, STATS>(so, L, sc.center(j), sc.r2(j), t0, t1, true, k)) { tr = 0; break; }
+                    if (j < n ? intersect_t<T, STATS>(so, L, sc.center(j), sc.r2(j), t0, t1, true, k)
+                              : (plane_t<T, STATS>(so, L, sc.pl_p(j - n), sc.pl_n(j - n), t0, k) && t0 * t0 < len2)) { tr = 0; break; }
                 }
                 T ratio = N.x * L.x + N.y * L.y + N.z * L.z;
                 ratio = (ratio != ratio) ? ratio : (ratio > 0 ? ratio : T(0));       // Math.max(0, .)
                 dif.x += (col.x * tr) * (ei.x * ratio);
                 dif.y += (col.y * tr) * (ei.y * ratio);
                 dif.z += (col.z * tr) * (ei.z * ratio);
+                if (ks > 0) {
+                    T sp = Rv.x * L.x + Rv.y * L.y + Rv.z * L.z;
+                    sp = (sp != sp) ? sp : (sp > 0 ? sp : T(0));
+                    T ph = 1, b = sp;
+                    for (unsigned q = sc.phong_exp(e, ne); q > 0; q >>= 1) { if (q & 1u) ph = ph * b; b = b * b; }
+                    const T kp = ks * ph;
+                    dif.x += tr * (ei.x * kp);
+                    dif.y += tr * (ei.y * kp);
+                    dif.z += tr * (ei.z * kp);
+                }
             }
             acc.x += r.w.x * dif.x; acc.y += r.w.y * dif.y; acc.z += r.w.z * dif.z;
         }
@@ -425,16 +493,18 @@ __device__ __forceinline__ void render_ext_pixel(const RenderArgs& a, int x, int
         normalize_v(d);
         xcount<STATS>(k, XT_CAMERA);
         V<T> c;
-        if constexpr (sizeof(T) == 4 && !STATS) {
+        bool done = false;
+        if constexpr (sizeof(T) == 4 && !STATS) if (sc.fv.h->n_planes == 0u && sc.fv.h->has_phong == 0u) {
+            // (scenes with planes or Phong terms take the general form below in float32 too)
+            done = true;
             const unsigned char* block = a.scenes + (uint64_t)(a.first_frame + frame) * a.frame_stride;
             __shared__ float ext_lds[PTR_EXT_LDS_ENTRIES * 640];          // (the float32 form runs one wave per workgroup)
             RayStack st;
             st.base = ext_lds + (threadIdx.x & 63);
             const V<float> cf = trace_ext_f32(st, block, a, V<float>{0, 0, 0}, V<float>{(float)d.x, (float)d.y, (float)d.z}, a.max_depth);
             c = V<T>{T(cf.x), T(cf.y), T(cf.z)};
-        } else {
-            c = trace_ext<T, STATS>(sc, origin, d, a.max_depth, k);
         }
+        if (!done) c = trace_ext<T, STATS>(sc, origin, d, a.max_depth, k);
         sum.x += c.x; sum.y += c.y; sum.z += c.z;
     }
     if (a.spp > 1) { const T k = T(a.spp); sum.x /= k; sum.y /= k; sum.z /= k; }

@@ -11,6 +11,7 @@
  *   setScene(h, Float64Array soa, n, nFrames)                                ptr_set_scene_sequence_f64
  *   setBackground(h, r, g, b)                                                ptr_set_background_f64
  *   setCamera(h, Float64Array(13) | null)                                    ptr_set_camera
+ *   setExtension(h, Float64Array planes | null, nPlanes, Float64Array phong | null, nElements)   ptr_set_extension_f64
  *   render(h, w, height, startY, scanHeight, flags)  -> ArrayBuffer (RGBA8)  ptr_render
  *   renderAsync(h, w, height, startY, scanHeight, flags) -> Promise<ArrayBuffer>
  *   traceSamples(h, Float64Array origin(3), Float64Array dirs) -> {rgb, rgb8, hit, normal}   ptr_trace_samples_f64
@@ -218,6 +219,27 @@ static napi_value js_set_camera(napi_env env, napi_callback_info info)
         cam.tan_half_fov = v[12];
         rc = ptr_set_camera(ctx, &cam);
     }
+    if (rc != PTR_OK) return throw_ptr(env, ctx, rc);
+    return NULL;
+}
+
+/* setExtension(h, Float64Array planes | null, nPlanes, Float64Array phong | null, nElements): planes and Phong terms
+ * (extension scene data, ptr_set_extension_f64) */
+static napi_value js_set_extension(napi_env env, napi_callback_info info)
+{
+    napi_value argv[5];
+    if (!get_args(env, info, 5, argv)) return NULL;
+    ptr_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    double *pl, *ph; size_t npl, nph;
+    int32_t n_planes, n_elements;
+    if (!get_f64_array(env, argv[1], &pl, &npl) || !get_i32(env, argv[2], &n_planes) ||
+        !get_f64_array(env, argv[3], &ph, &nph) || !get_i32(env, argv[4], &n_elements)) return NULL;
+    if (n_planes < 0 || n_elements < 0 || (n_planes > 0 && npl < (size_t)14 * (size_t)n_planes) || (ph && nph < (size_t)2 * (size_t)n_elements)) {
+        napi_throw_range_error(env, "PTR_ERR_INVALID", "planes must hold 14 * nPlanes numbers and phong 2 * nElements");
+        return NULL;
+    }
+    int rc = ptr_set_extension_f64(ctx, n_planes > 0 ? pl : NULL, n_planes, ph, n_elements);
     if (rc != PTR_OK) return throw_ptr(env, ctx, rc);
     return NULL;
 }
@@ -623,7 +645,7 @@ NAPI_MODULE_INIT()
 {
     const struct { const char *name; napi_callback fn; } fns[] = {
         {"create", js_create}, {"destroy", js_destroy}, {"setScene", js_set_scene},
-        {"setBackground", js_set_background}, {"setCamera", js_set_camera}, {"render", js_render},
+        {"setBackground", js_set_background}, {"setCamera", js_set_camera}, {"setExtension", js_set_extension}, {"render", js_render},
         {"renderAsync", js_render_async}, {"traceBatch", js_trace_batch}, {"traceSamples", js_trace_samples}, {"rcReproject", js_rc_reproject}, {"rcShade", js_rc_shade}, {"stats", js_stats},
         {"commInitAll", js_comm_init_all}, {"renderMulti", js_render_multi},
     };

@@ -2,6 +2,7 @@
 export { default as Vector3 } from './src/Vector3.js';
 export { default as Material } from './src/Material.js';
 export { default as Sphere } from './src/Sphere.js';
+export { default as Plane } from './src/Plane.js';          // extension primitive (not in the reference)
 export { default as Scene } from './src/Scene.js';
 export { default as Color } from './src/Color.js';
 export { default as Camera } from './src/Camera.js';

@@ -1,6 +1,7 @@
 import Vector3 from './Vector3.js';
 import Color from './Color.js';
 import native from './native.js';
+import Plane from './Plane.js';
 
 /**
  * RayTracer — drop-in for raytracer-js-master/src/RayTracer.js:11-199 whose per-pixel loop runs on
@@ -62,10 +63,34 @@ export default class RayTracer {
         return soa;
     }
 
+    // extension data: planes as 14 rows (px py pz nx ny nz sr sg sb refl transp er eg eb), Phong terms as ks[] then exponent[]
+    static flattenPlanes(planes) {
+        const n = planes.length, soa = new Float64Array(14 * n);
+        planes.forEach((pl, i) => {
+            const p = pl.point, nr = pl.normal, m = pl.material, sc = m.surfaceColor, ec = m.emissionColor;
+            [p.x, p.y, p.z, nr.x, nr.y, nr.z, sc.x, sc.y, sc.z, m.reflection, m.transparency, ec.x, ec.y, ec.z]
+                .forEach((v, row) => { soa[row * n + i] = v; });
+        });
+        return soa;
+    }
+
     _upload(useCamera) {
         if (!this._handle) throw new Error('RayTracer was disposed');
-        const elements = this.scene.getElements();
+        const all = this.scene.getElements();
+        const planes = all.filter(el => el instanceof Plane);
+        const elements = planes.length ? all.filter(el => !(el instanceof Plane)) : all;     // spheres first, then planes
         this._native.setScene(this._handle, RayTracer.flatten(elements), elements.length, 1);
+        const ordered = planes.length ? elements.concat(planes) : elements;
+        const phong = ordered.some(el => el.material.specular > 0);
+        if (planes.length || phong || this._hasExtension) {
+            let ph = null;
+            if (phong) {
+                ph = new Float64Array(2 * ordered.length);
+                ordered.forEach((el, i) => { ph[i] = el.material.specular || 0; ph[ordered.length + i] = el.material.shininess || 1; });
+            }
+            this._native.setExtension(this._handle, planes.length ? RayTracer.flattenPlanes(planes) : null, planes.length, ph, ordered.length);
+            this._hasExtension = planes.length > 0 || phong;
+        }
         const bg = this.backgroundColor;
         this._native.setBackground(this._handle, bg.x, bg.y, bg.z);
         if (useCamera && this.camera) {

@@ -6,7 +6,7 @@ import fs from 'fs';
 import path from 'path';
 import { fileURLToPath } from 'url';
 import assert from 'assert';
-import { Vector3, Material, Sphere, Scene, Color, Camera, RayTracer, RenderPlanner, RenderCache, RenderCacheDriver, RcCamera } from '../index.js';
+import { Plane, Vector3, Material, Sphere, Scene, Color, Camera, RayTracer, RenderPlanner, RenderCache, RenderCacheDriver, RcCamera } from '../index.js';
 
 const here = path.dirname(fileURLToPath(import.meta.url));
 const golden = path.join(here, '..', '..', '..', 'tests', 'golden');
@@ -412,6 +412,38 @@ async function gpuTests() {
         planner.updateScene();
         assert.ok(sameBytes(new Uint8Array(planner.renderFrameGathered()), new Uint8Array(rt.renderFrame(200, 77))));
         rt.dispose(); planner.dispose();
+    });
+    test('Plane + Phong materials (extension): renderFrame equals the frozen specification frames', () => {
+        // synthetic.planes_scene() of the Python side, built with the JS classes (tests/golden/ext: self-pinned, not reference parity)
+        const ext = JSON.parse(fs.readFileSync(path.join(golden, 'ext', 'index.json'))).cases;
+        const ex = scenes.example1.elements;
+        const scene = new Scene();
+        const ks = [0.6, 0.4, 0.5, 0.3, 0, 0], sh = [32, 37, 1, 128, 1, 1];
+        // a plane added FIRST still counts after all spheres
+        scene.add(new Plane(new Vector3(0, -4, 0), new Vector3(0, 2, 0), new Material(new Vector3(0.2, 0.2, 0.2), 0, 0, new Vector3(), 0.25, 8)));
+        for (let i = 1; i < 7; i++) {
+            const s = Sphere.deserialize(ex[i]);
+            s.material = new Material(s.material.surfaceColor, s.material.reflection, s.material.transparency, s.material.emissionColor, ks[i - 1], sh[i - 1]);
+            scene.add(s);
+        }
+        scene.add(new Plane(new Vector3(0, 0, -45), new Vector3(0, 0, 1), new Material(new Vector3(0.8, 0.8, 0.9), 1, 0, new Vector3())));
+        scene.add(new Plane(new Vector3(30, 25, -20), new Vector3(-0.6, -0.8, 0), new Material(new Vector3(), 0, 0, new Vector3(0.3, 0.25, 0.2))));
+        const rt = new RayTracer(new Vector3(2, 2, 2), scene);
+        for (const key of ['planes_phong@160x120_d0_s1', 'planes_phong@160x120_d3_s2']) {
+            const c = ext[key];
+            const got = new Uint8Array(rt.renderFrame(c.width, c.height, { maxDepth: c.max_depth, spp: c.spp, seed: c.seed }));
+            assert.ok(sameBytes(got, u8(c.file)), key);
+        }
+        assert.throws(() => rt.render(64, 48), RangeError);             // render() keeps the reference's semantics: no planes there
+        const pl = scene.getElements()[0];
+        const out = { t0: 1e8, t1: 1e8 };
+        assert.ok(pl.intersect(new Vector3(0, 0, 0), new Vector3(0, -1, 0), out) && out.t0 === 4);
+        assert.ok(!pl.intersect(new Vector3(0, 0, 0), new Vector3(0, 1, 0), out));
+        assert.deepStrictEqual(Plane.deserialize(pl.serialize()).serialize(), pl.serialize());
+        // back to a scene without extension data: the reference path again
+        rt.scene = buildExample1();
+        assert.ok(sameBytes(new Uint8Array(rt.render(64, 48)), u8(index.frames['example1@64x48'].file)));
+        rt.dispose();
     });
     test('stats(): the reference ray mix at 640x480 (SURVEY 6)', () => {
         const rt = new RayTracer(new Vector3(2, 2, 2), buildExample1());

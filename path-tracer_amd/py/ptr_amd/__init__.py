@@ -26,7 +26,7 @@ OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NO_SCENE, ERR_UNSUPPORTED = 0, -1, 
 SYMBOLS = [
     "ptr_abi_version", "ptr_create", "ptr_destroy", "ptr_last_error",
     "ptr_set_scene", "ptr_set_scene_f64", "ptr_set_scene_sequence_f64",
-    "ptr_set_background", "ptr_set_background_f64", "ptr_set_camera",
+    "ptr_set_background", "ptr_set_background_f64", "ptr_set_camera", "ptr_set_extension_f64",
     "ptr_render", "ptr_render_device", "ptr_render_device_noalloc", "ptr_render_strips_device", "ptr_strip_rows", "ptr_strip_image_row", "ptr_sync",
     "ptr_trace_batch", "ptr_trace_batch_f64", "ptr_trace_samples_f64", "ptr_rc_reproject", "ptr_rc_reproject_device", "ptr_rc_shade", "ptr_rc_shade_device", "ptr_get_stats", "ptr_get_kernel_ms",
     "ptr_comm_unique_id", "ptr_comm_init_rank", "ptr_comm_init_all", "ptr_comm_destroy",
@@ -126,6 +126,7 @@ def lib():
         L.ptr_set_background.argtypes = [vp, fp]
         L.ptr_set_background_f64.argtypes = [vp, dp]
         L.ptr_set_camera.argtypes = [vp, C.POINTER(Camera)]
+        L.ptr_set_extension_f64.argtypes = [vp, dp, C.c_int, dp, C.c_int]
         L.ptr_render.argtypes = [vp, C.POINTER(Params), C.POINTER(C.c_uint32), fp]
         L.ptr_render_device.argtypes = [vp, C.POINTER(Params), C.c_int, C.c_int, vp, vp, vp]
         L.ptr_render_device_noalloc.argtypes = [vp, C.POINTER(Params), C.c_int, C.c_int, vp, vp, vp]
@@ -241,6 +242,13 @@ class Renderer:
     def set_background(self, rgb):
         rgb = np.ascontiguousarray(rgb, dtype=np.float64)
         self._check(self._L.ptr_set_background_f64(self._h, _dp(rgb)))
+
+    def set_extension(self, planes=None, phong=None):
+        """planes: (14, n_planes) rows px py pz nx ny nz sr sg sb refl transp er eg eb; phong: (2, n_elements) rows ks, exponent"""
+        pl = None if planes is None else np.ascontiguousarray(planes, dtype=np.float64)
+        ph = None if phong is None else np.ascontiguousarray(phong, dtype=np.float64)
+        self._check(self._L.ptr_set_extension_f64(self._h, _dp(pl) if pl is not None else None, 0 if pl is None else pl.shape[1],
+                                                  _dp(ph) if ph is not None else None, 0 if ph is None else ph.shape[1]))
 
     def set_camera(self, origin=None, right=(1, 0, 0), up=(0, 1, 0), forward=(0, 0, -1), tan_half_fov=None):
         if origin is None:

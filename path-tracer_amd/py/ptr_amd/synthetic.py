@@ -71,3 +71,26 @@ def many_spheres(n=10000, key=0xC0FFEE):
     soa[:, n - 2] = EXAMPLE1[5]
     soa[:, n - 1] = EXAMPLE1[6]
     return np.ascontiguousarray(soa)
+
+
+def planes_scene():
+    """Planes + Phong terms (extension data, include/ptr.h): the example scene's coloured spheres and lights over a floor
+    PLANE y = -4 (instead of the radius-10000 sphere), a mirror wall z = -45, a tilted emissive panel; Phong highlights on
+    the spheres (even, odd and unit exponents) and on the floor.  Returns (soa (12, 6), planes (14, 3), phong (2, 9))."""
+    soa = np.ascontiguousarray(EXAMPLE1[1:].T)                  # without the floor sphere: 4 spheres + 2 lights
+    # the panel's normal as Plane's constructor makes it from (-0.6, -0.8, 0): Vector3.normalize, invLen = 1 / sqrt(len2)
+    raw = (-0.6, -0.8, 0.0)
+    inv = 1.0 / np.sqrt(raw[0] * raw[0] + raw[1] * raw[1] + raw[2] * raw[2])
+    pn = [raw[0] * inv, raw[1] * inv, raw[2] * inv]
+    planes = np.array([
+        # px   py    pz     nx   ny        nz        sr    sg    sb   refl transp  er   eg   eb
+        [0.0, -4.0, 0.0,   0.0, 1.0,      0.0,      0.2,  0.2,  0.2, 0.0, 0.0,   0.0, 0.0, 0.0],
+        [0.0, 0.0, -45.0,  0.0, 0.0,      1.0,      0.8,  0.8,  0.9, 1.0, 0.0,   0.0, 0.0, 0.0],
+        [30.0, 25.0, -20.0, pn[0], pn[1], pn[2],    0.0,  0.0,  0.0, 0.0, 0.0,   0.3, 0.25, 0.2],
+    ]).T
+    n = soa.shape[1] + planes.shape[1]
+    phong = np.zeros((2, n))
+    phong[1] = 1.0
+    phong[0, 0:4] = [0.6, 0.4, 0.5, 0.3]; phong[1, 0:4] = [32, 37, 1, 128]
+    phong[0, 6] = 0.25; phong[1, 6] = 8                         # the floor plane
+    return soa, np.ascontiguousarray(planes), phong

@@ -172,6 +172,48 @@ def test_baseline_config3_one_part_of_4k_256spp(rdr, golden_dir):
     assert _psnr(frames[F], frames[X]) >= 50.0 and _rmse(frames[F], frames[X]) <= 0.5
 
 
+def test_planes_and_phong_against_the_specification(rdr, golden_dir):
+    """ray-plane primitive + Phong terms (north_star names both; the reference has neither: self-pinned like the bounce
+    loop).  float64 (default mode): the frozen frames of the CPU specification; float32 by name: PSNR >= 50 dB; the
+    extension data is cleared again and the reference path is back."""
+    from ptr_amd import synthetic as syn
+    soa, planes, phong = syn.planes_scene()
+    idx = _index(golden_dir)
+    rdr.set_camera(None); rdr.set_scene(soa); rdr.set_background(syn.BACKGROUND)
+    rdr.set_extension(planes, phong)
+    try:
+        for key in ("planes_phong@160x120_d0_s1", "planes_phong@160x120_d3_s2", "planes_phong@640x480_d5_s1"):
+            c = idx[key]
+            kw = dict(max_depth=c["max_depth"], spp=c["spp"], seed=c["seed"])
+            got = rdr.render(c["width"], c["height"], flags=0, **kw)
+            assert hashlib.sha256(got.tobytes()).hexdigest() == c["sha256"], key
+            if "file" in c:
+                assert np.array_equal(got, np.fromfile(os.path.join(golden_dir, c["file"]), dtype=np.uint32)), key
+            f32 = rdr.render(c["width"], c["height"], flags=ptr_amd.MODE_F32_ONLY, **kw)
+            print(f"{key}: float32 PSNR {_psnr(f32, got):.1f} dB")
+            assert _psnr(f32, got) >= 50.0
+        # the picture really has a floor plane and highlights: it differs from the same spheres without the extension data
+        with_ext = rdr.render(160, 120, flags=0)
+        # random planes / Phong terms against the CPU specification, straight
+        rng = np.random.default_rng(5)
+        for t in range(3):
+            pl = planes.copy(); pl[1, 0] = -4.0 - t; pl[6:9, 1] = rng.uniform(0.2, 1.0, 3)
+            ph = phong.copy(); ph[0] = rng.uniform(0, 0.8, ph.shape[1]); ph[1] = rng.integers(1, 200, ph.shape[1])
+            rdr.set_extension(pl, ph)
+            got = rdr.render(96, 64, flags=0, max_depth=2 + t, spp=1 + t, seed=t)
+            want = orc.render_ext2(soa, syn.BACKGROUND, 96, 64, planes=pl, phong=ph, max_depth=2 + t, spp=1 + t, seed=t)
+            assert np.array_equal(got, want), t
+        with pytest.raises(ptr_amd.PtrError):
+            rdr.trace_batch_f64(np.array([[0.0, 0.0, -1.0]]))            # single rays: reference semantics only
+        with pytest.raises(ptr_amd.PtrError):
+            rdr.set_extension(planes, phong[:, :4]); rdr.render(32, 32, flags=0)      # Phong terms for the wrong element count
+    finally:
+        rdr.set_extension(None, None)
+    plain = rdr.render(160, 120, flags=0)
+    assert np.array_equal(plain, orc.render(soa, syn.BACKGROUND, 160, 120, flags=0))   # the reference path again
+    assert not np.array_equal(plain, with_ext)
+
+
 def test_work_counters_match_the_specification(rdr, scenes):
     for name, depth, spp in (("example1", 5, 1), ("random_3", 3, 2), ("example1", 0, 1)):
         sc = scenes[name]
