@@ -393,6 +393,71 @@ int ptr_rc_shade_device(ptr_ctx *ctx, const ptr_rc_shade_params *params, int n_i
                         void *d_pixel_priority, void *d_hist, void *d_totals, void *d_color_frame,
                         void *d_reprojection_frame, void *d_priority_frame, void *stream);
 
+/* ---- render cache: the frame loop on a cache that stays on the GPU (SURVEY.md 8f ranks 1-4 together) ----------- */
+
+/* Driver.nextFrame() (rendercache-js/src/Driver.js:95-115) with the cache (Driver.cache, Sample.js) and the pixel grid
+ * (Driver.buffer, Pixel.js) resident in HBM: per frame the camera state goes down and eight numbers come back; the
+ * frames come up when a getter asks for them.  Same state after every frame as the reference's sequential loop:
+ *   reprojectFrame (:417-486) and depthCulling + fillGaps (:488-679)   the passes of ptr_rc_reproject / ptr_rc_shade;
+ *   directSamples (:682-827)    threshold over the priority histograms (:690-706), candidate pixels in the serpentine
+ *                               walk order, picks at Math.round of a running sum of the request factor, the error
+ *                               diffusion of distributeExceedingPriority (:829-839) with the stale pixel of :813-814;
+ *   addRequest / allocCacheItem (:252-326)   pages of 8 items, the first empty one or the oldest, Sample.clear();
+ *   requestSamples (:842-863)   Camera.computeDirToXY (Camera.js:39-50) + the trace of ptr_trace_samples_f64, colour
+ *                               bytes and hit point into the item, the colour into the item's pixel;
+ *   age (:936-942) of every item, getCacheUsage, the frame getters (:960-1046).
+ * The first frame's initializeCache (:328-353) draws pixels from Math.random and stays with the caller: fill the cache
+ * on the host (ptr_trace_samples_f64), then hand the state over with ptr_rc_cache_upload.
+ *
+ * Layout (as ptr_rc_reproject / ptr_rc_shade): n_items cache items — item_pixel (grid index or -1), item_hit_xyz
+ * (3 doubles, NaN in x = none), item_age, item_rgb (r | g << 8 | b << 16); the padded grid of (width + 2) * (height + 2)
+ * pixels — pixel_element (cache index or -1), pixel_depth, pixel_rgb, pixel_priority, pixel_sample (0 / 1).
+ * cache_pointer = Driver.cachePointer.  One cache per context; it uses the context's scene (ptr_set_scene*: spheres
+ * only, as the reference) and stream.  n_items >= 8, priority_max an integer in 0..255.                            */
+typedef struct ptr_rc_view {
+    double from[3];                 /* camera.from                                                           */
+    double world[16];               /* cam.matrixWorld.elements (column-major, as THREE.Matrix4 stores them) */
+    double world_inv[16];           /* cam.matrixWorldInverse                                                */
+    double proj[16];                /* cam.projectionMatrix                                                  */
+    double proj_inv[16];            /* cam.projectionMatrixInverse                                           */
+} ptr_rc_view;
+
+typedef struct ptr_rc_loop_params {
+    double age_factor;              /* Driver.ageFactor (1)                                                  */
+    double depth_threshold;         /* Driver.depthThreshold (1e6)                                           */
+    double interpolation_zero;      /* Driver.interpolationZero (20)                                         */
+    double interpolation_random;    /* Driver.interpolationRandom (5)                                        */
+    double priority_max;            /* Driver.priorityMax (255)                                              */
+    double max_samples_per_frame;   /* Driver.maximumSamplesPerFrame (scope.x * scope.y / ratio)             */
+} ptr_rc_loop_params;
+
+typedef struct ptr_rc_frame_stats { /* Driver.statistics after the frame                                     */
+    double threshold;               /* NaN = null                                                            */
+    double request_factor, candidates, requests, completeness, total_priority;
+    double total_priority_increment;/* what the frame added to Driver.totalPriority                          */
+    double cache_usage;             /* getCacheUsage()                                                       */
+} ptr_rc_frame_stats;
+
+int  ptr_rc_cache_create(ptr_ctx *ctx, int width, int height, int n_items);
+void ptr_rc_cache_destroy(ptr_ctx *ctx);
+int  ptr_rc_cache_shape(ptr_ctx *ctx, int *width, int *height, int *n_items);     /* what the cache was created with */
+/* HOST pointers, all required; both wait. */
+int  ptr_rc_cache_upload(ptr_ctx *ctx, const int32_t *item_pixel, const double *item_hit_xyz, const double *item_age,
+                         const uint32_t *item_rgb, const int32_t *pixel_element, const double *pixel_depth,
+                         const uint32_t *pixel_rgb, const int32_t *pixel_priority, const uint8_t *pixel_sample,
+                         int64_t cache_pointer);
+int  ptr_rc_cache_download(ptr_ctx *ctx, int32_t *item_pixel, double *item_hit_xyz, double *item_age, uint32_t *item_rgb,
+                           int32_t *pixel_element, double *pixel_depth, uint32_t *pixel_rgb, int32_t *pixel_priority,
+                           uint8_t *pixel_sample, int64_t *cache_pointer);
+/* One frame; waits for it.  The reference's pick loop does not end when the request factor is 0 while candidates
+ * exist (every priority outside 0..255): that state is refused with PTR_ERR_INVALID, the cache is then as the
+ * shading pass left it.                                                                                         */
+int  ptr_rc_next_frame(ptr_ctx *ctx, const ptr_rc_view *view, const ptr_rc_loop_params *params, ptr_rc_frame_stats *out);
+/* getColorFrame / getReprojectionFrame / getPriorityFrame / getSamplingFrame (:960-1046) from the live state: width *
+ * height RGBA8 words each, rows bottom-up, HOST pointers, any may be NULL.                                       */
+int  ptr_rc_get_frames(ptr_ctx *ctx, uint32_t *color_frame, uint32_t *reprojection_frame, uint32_t *priority_frame,
+                       uint32_t *sampling_frame);
+
 /* ---- introspection ----------------------------------------------------------------------- */
 int ptr_get_stats(ptr_ctx *ctx, ptr_stats *out);
 

@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -29,6 +30,20 @@ thread_local char g_create_error[512] = "";      // fixed buffers: reporting an 
 struct DeviceBuffer {
     void*  ptr = nullptr;
     size_t bytes = 0;
+};
+
+// The render cache when it lives on the GPU (ptr_rc_cache_*, ptr_rc_next_frame): Driver.cache and Driver.buffer as flat
+// arrays, the words and lists one frame's passes hand to each other, and two pinned host buffers for what crosses PCIe.
+struct RcCache {
+    int width = 0, height = 0, n_items = 0;
+    bool loaded = false;
+    DeviceBuffer item_pixel, item_hit, item_age, item_rgb;                                  // n_items
+    DeviceBuffer pixel_element, pixel_depth, pixel_rgb, pixel_priority, pixel_sample;       // (width + 2) * (height + 2)
+    DeviceBuffer words;                                                                     // RC_WORDS_*
+    DeviceBuffer cand, picks, pick_item, need, rank, dirs, tr_rgb, tr_hit;                  // up to width * height requests
+    DeviceBuffer frames, temp;
+    unsigned char* host_words = nullptr;
+    int32_t* host_picks = nullptr;
 };
 
 // layout of ptr_ctx::words (device): two queue counters on lines of their own, then the stats
@@ -80,6 +95,7 @@ struct ptr_ctx {
     DeviceBuffer rc_hit, rc_age, rc_item, rc_pel, rc_pdep;           // staging for ptr_rc_reproject (host buffers)
     DeviceBuffer rc_rgb, rc_prgb, rc_pprio, rc_hist, rc_frames;      // staging for ptr_rc_shade (host buffers)
     DeviceBuffer rc_page;                                            // scratch of ptr_rc_shade*: per-pixel element age
+    RcCache* rcc = nullptr;                                          // ptr_rc_cache_create
     std::vector<unsigned char> host_blocks;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // PTR_FLAG_TIMING
     int timed_kernels = 0;             // kernels bracketed by ev[] in the last timed call
@@ -125,6 +141,20 @@ int grow(ptr_ctx* c, DeviceBuffer& b, size_t bytes)
     HIP_TRY(c, hipMalloc(&b.ptr, bytes));
     b.bytes = bytes;
     return PTR_OK;
+}
+
+void rc_cache_free(ptr_ctx* c)
+{
+    RcCache* r = c->rcc;
+    if (!r) return;
+    for (DeviceBuffer* b : {&r->item_pixel, &r->item_hit, &r->item_age, &r->item_rgb, &r->pixel_element, &r->pixel_depth, &r->pixel_rgb,
+                            &r->pixel_priority, &r->pixel_sample, &r->words, &r->cand, &r->picks, &r->pick_item, &r->need, &r->rank,
+                            &r->dirs, &r->tr_rgb, &r->tr_hit, &r->frames, &r->temp})
+        if (b->ptr) (void)hipFree(b->ptr);
+    if (r->host_words) (void)hipHostFree(r->host_words);
+    if (r->host_picks) (void)hipHostFree(r->host_picks);
+    delete r;
+    c->rcc = nullptr;
 }
 
 void default_camera(ptr_camera& cam)
@@ -670,6 +700,7 @@ void ptr_destroy(ptr_ctx* c)
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
     if (c->have_last) (void)hipEventSynchronize(c->last_ev);     // kernels enqueued on a caller's stream still read our buffers
     if (c->comm) (void)ptr_comm_destroy(c);
+    rc_cache_free(c);
     for (DeviceBuffer* b : {&c->gather_stage, &c->multi_local, &c->multi_full, &c->scenes, &c->queue, &c->words, &c->out8, &c->out32f, &c->tr_in_o,
                             &c->tr_in_d, &c->tr_rgb, &c->tr_el, &c->tr_hit, &c->tr_nrm, &c->rc_depth, &c->rc_keys,
                             &c->rc_temp, &c->rc_hit, &c->rc_age, &c->rc_item, &c->rc_pel, &c->rc_pdep, &c->rc_rgb,
@@ -1170,6 +1201,268 @@ int ptr_rc_reproject(ptr_ctx* c, const ptr_rc_camera* cam, int n_items, const do
     }
     HIP_TRY(c, hipMemcpyAsync(pixel_element, c->rc_pel.ptr, cells * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(pixel_depth, c->rc_pdep.ptr, cells * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return PTR_OK;
+}
+
+// ---- render cache: the frame loop on a resident cache ------------------------------------------------------------
+namespace {
+int rc_cache_ready(ptr_ctx* c, bool need_state)
+{
+    if (!c->rcc) return fail(c, PTR_ERR_INVALID, "no render cache on this context (ptr_rc_cache_create)");
+    if (need_state && !c->rcc->loaded) return fail(c, PTR_ERR_INVALID, "the render cache has no state yet (ptr_rc_cache_upload)");
+    return PTR_OK;
+}
+
+RcLoopArgs rc_loop_args(const RcCache& r)
+{
+    RcLoopArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.width = r.width; a.height = r.height; a.n_items = r.n_items;
+    a.pages = r.n_items / 8;
+    a.item_pixel = static_cast<int32_t*>(r.item_pixel.ptr); a.item_hit = static_cast<double*>(r.item_hit.ptr);
+    a.item_age = static_cast<double*>(r.item_age.ptr); a.item_rgb = static_cast<uint32_t*>(r.item_rgb.ptr);
+    a.pixel_element = static_cast<int32_t*>(r.pixel_element.ptr); a.pixel_rgb = static_cast<uint32_t*>(r.pixel_rgb.ptr);
+    a.pixel_priority = static_cast<int32_t*>(r.pixel_priority.ptr); a.pixel_sample = static_cast<uint8_t*>(r.pixel_sample.ptr);
+    unsigned char* w = static_cast<unsigned char*>(r.words.ptr);
+    a.hist = reinterpret_cast<const uint32_t*>(w + RC_WORDS_HIST);
+    a.words = reinterpret_cast<RcLoopWords*>(w + RC_WORDS_LOOP);
+    a.cand = static_cast<int32_t*>(r.cand.ptr); a.pick_index = static_cast<const int32_t*>(r.picks.ptr);
+    a.pick_item = static_cast<int32_t*>(r.pick_item.ptr); a.need = static_cast<int32_t*>(r.need.ptr); a.rank = static_cast<int32_t*>(r.rank.ptr);
+    a.dirs = static_cast<double*>(r.dirs.ptr); a.tr_rgb = static_cast<const double*>(r.tr_rgb.ptr); a.tr_hit = static_cast<const double*>(r.tr_hit.ptr);
+    return a;
+}
+}  // namespace
+
+int ptr_rc_cache_create(ptr_ctx* c, int width, int height, int n_items)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (width < 1 || height < 1 || (long long)(width + 2) * (height + 2) >= (1ll << 31))
+        return fail(c, PTR_ERR_INVALID, "bad frame size %d x %d", width, height);
+    if (n_items < 8) return fail(c, PTR_ERR_INVALID, "a render cache needs at least one page of 8 items (n_items = %d)", n_items);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    rc_cache_free(c);
+    RcCache* r = new (std::nothrow) RcCache();
+    if (!r) return fail(c, PTR_ERR_INVALID, "out of host memory");
+    c->rcc = r;
+    r->width = width; r->height = height; r->n_items = n_items;
+    const size_t n = (size_t)n_items, cells = (size_t)(width + 2) * (size_t)(height + 2), px = (size_t)width * (size_t)height;
+    const size_t temp = rc_loop_temp_bytes(width, height);
+    int rc = PTR_OK;
+    const struct { DeviceBuffer* b; size_t bytes; } want[] = {
+        {&r->item_pixel, n * 4}, {&r->item_hit, n * 24}, {&r->item_age, n * 8}, {&r->item_rgb, n * 4},
+        {&r->pixel_element, cells * 4}, {&r->pixel_depth, cells * 8}, {&r->pixel_rgb, cells * 4}, {&r->pixel_priority, cells * 4},
+        {&r->pixel_sample, cells}, {&r->words, RC_WORDS_BYTES}, {&r->cand, px * 4}, {&r->picks, px * 4}, {&r->pick_item, px * 4},
+        {&r->need, px * 4}, {&r->rank, px * 4}, {&r->dirs, px * 24}, {&r->tr_rgb, px * 24}, {&r->tr_hit, px * 24},
+        {&r->frames, 4 * px * 4}, {&r->temp, temp > 0 ? temp : 16}};
+    for (const auto& w : want)
+        if (rc == PTR_OK) rc = grow(c, *w.b, w.bytes);
+    if (rc == PTR_OK && hipHostMalloc(reinterpret_cast<void**>(&r->host_words), RC_WORDS_BYTES, hipHostMallocDefault) != hipSuccess)
+        rc = fail(c, PTR_ERR_HIP, "hipHostMalloc failed for the render cache's words");
+    if (rc == PTR_OK && hipHostMalloc(reinterpret_cast<void**>(&r->host_picks), px * 4, hipHostMallocDefault) != hipSuccess)
+        rc = fail(c, PTR_ERR_HIP, "hipHostMalloc failed for the render cache's pick list");
+    if (rc == PTR_OK && temp == 0) rc = fail(c, PTR_ERR_HIP, "hipCUB did not report its temporary storage size");
+    if (rc != PTR_OK) { (void)hipGetLastError(); rc_cache_free(c); }
+    return rc;
+}
+
+void ptr_rc_cache_destroy(ptr_ctx* c)
+{
+    if (!c) return;
+    std::lock_guard<std::mutex> g(c->mu);
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    rc_cache_free(c);
+}
+
+int ptr_rc_cache_shape(ptr_ctx* c, int* width, int* height, int* n_items)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    PTR_TRY(rc_cache_ready(c, false));
+    if (!width || !height || !n_items) return fail(c, PTR_ERR_INVALID, "output pointer is NULL");
+    *width = c->rcc->width; *height = c->rcc->height; *n_items = c->rcc->n_items;
+    return PTR_OK;
+}
+
+int ptr_rc_cache_upload(ptr_ctx* c, const int32_t* item_pixel, const double* item_hit, const double* item_age, const uint32_t* item_rgb,
+                        const int32_t* pixel_element, const double* pixel_depth, const uint32_t* pixel_rgb, const int32_t* pixel_priority,
+                        const uint8_t* pixel_sample, int64_t cache_pointer)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    PTR_TRY(rc_cache_ready(c, false));
+    RcCache& r = *c->rcc;
+    if (!item_pixel || !item_hit || !item_age || !item_rgb || !pixel_element || !pixel_depth || !pixel_rgb || !pixel_priority || !pixel_sample)
+        return fail(c, PTR_ERR_INVALID, "a required buffer is NULL");
+    if (cache_pointer < 0 || cache_pointer % 8 != 0 || cache_pointer > (int64_t)r.n_items)
+        return fail(c, PTR_ERR_INVALID, "cache_pointer must be a multiple of 8 in 0..n_items");
+    const size_t n = (size_t)r.n_items, cells = (size_t)(r.width + 2) * (size_t)(r.height + 2);
+    for (size_t i = 0; i < n; i++)
+        if (item_pixel[i] < -1 || (size_t)(item_pixel[i] + 1) > cells)
+            return fail(c, PTR_ERR_INVALID, "item_pixel[%zu] = %d is not a pixel of the grid", i, item_pixel[i]);
+    for (size_t p = 0; p < cells; p++)
+        if (pixel_element[p] < -1 || (size_t)(pixel_element[p] + 1) > n)
+            return fail(c, PTR_ERR_INVALID, "pixel_element[%zu] = %d is not a cache item", p, pixel_element[p]);
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const struct { void* dst; const void* src; size_t bytes; } up[] = {
+        {r.item_pixel.ptr, item_pixel, n * 4}, {r.item_hit.ptr, item_hit, n * 24}, {r.item_age.ptr, item_age, n * 8},
+        {r.item_rgb.ptr, item_rgb, n * 4}, {r.pixel_element.ptr, pixel_element, cells * 4}, {r.pixel_depth.ptr, pixel_depth, cells * 8},
+        {r.pixel_rgb.ptr, pixel_rgb, cells * 4}, {r.pixel_priority.ptr, pixel_priority, cells * 4}, {r.pixel_sample.ptr, pixel_sample, cells}};
+    for (const auto& u : up) HIP_TRY(c, hipMemcpyAsync(u.dst, u.src, u.bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemsetAsync(r.words.ptr, 0, RC_WORDS_BYTES, s));
+    const int32_t page_next = (int32_t)((cache_pointer / 8) % (int64_t)(r.n_items / 8));
+    HIP_TRY(c, hipMemcpyAsync(static_cast<unsigned char*>(r.words.ptr) + RC_WORDS_LOOP + offsetof(RcLoopWords, page_next), &page_next,
+                              sizeof page_next, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    r.loaded = true;
+    return PTR_OK;
+}
+
+int ptr_rc_cache_download(ptr_ctx* c, int32_t* item_pixel, double* item_hit, double* item_age, uint32_t* item_rgb, int32_t* pixel_element,
+                          double* pixel_depth, uint32_t* pixel_rgb, int32_t* pixel_priority, uint8_t* pixel_sample, int64_t* cache_pointer)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    PTR_TRY(rc_cache_ready(c, true));
+    RcCache& r = *c->rcc;
+    if (!item_pixel || !item_hit || !item_age || !item_rgb || !pixel_element || !pixel_depth || !pixel_rgb || !pixel_priority ||
+        !pixel_sample || !cache_pointer)
+        return fail(c, PTR_ERR_INVALID, "a required buffer is NULL");
+    const size_t n = (size_t)r.n_items, cells = (size_t)(r.width + 2) * (size_t)(r.height + 2);
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const struct { void* dst; const void* src; size_t bytes; } down[] = {
+        {item_pixel, r.item_pixel.ptr, n * 4}, {item_hit, r.item_hit.ptr, n * 24}, {item_age, r.item_age.ptr, n * 8},
+        {item_rgb, r.item_rgb.ptr, n * 4}, {pixel_element, r.pixel_element.ptr, cells * 4}, {pixel_depth, r.pixel_depth.ptr, cells * 8},
+        {pixel_rgb, r.pixel_rgb.ptr, cells * 4}, {pixel_priority, r.pixel_priority.ptr, cells * 4}, {pixel_sample, r.pixel_sample.ptr, cells}};
+    for (const auto& d : down) HIP_TRY(c, hipMemcpyAsync(d.dst, d.src, d.bytes, hipMemcpyDeviceToHost, s));
+    int32_t page_next = 0;
+    HIP_TRY(c, hipMemcpyAsync(&page_next, static_cast<unsigned char*>(r.words.ptr) + RC_WORDS_LOOP + offsetof(RcLoopWords, page_next),
+                              sizeof page_next, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    *cache_pointer = (int64_t)page_next * 8;        // (the pointer after the last page and 0 name the same next page)
+    return PTR_OK;
+}
+
+int ptr_rc_next_frame(ptr_ctx* c, const ptr_rc_view* view, const ptr_rc_loop_params* par, ptr_rc_frame_stats* out)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    PTR_TRY(rc_cache_ready(c, true));
+    if (!view || !par || !out) return fail(c, PTR_ERR_INVALID, "view / params / out is NULL");
+    if (!c->have_scene) return fail(c, PTR_ERR_NO_SCENE, "no scene uploaded (call ptr_set_scene* first)");
+    if (c->n_planes > 0 || c->n_phong > 0)
+        return fail(c, PTR_ERR_UNSUPPORTED, "the render cache traces with the reference's semantics (spheres, Lambert): clear the planes / "
+                                            "Phong terms (ptr_set_extension_f64(ctx, NULL, 0, NULL, 0)) first");
+    if (!(par->priority_max >= 0 && par->priority_max <= 255) || par->priority_max != std::floor(par->priority_max))
+        return fail(c, PTR_ERR_INVALID, "priority_max must be an integer in 0..255");
+    if (!(par->max_samples_per_frame > 0)) return fail(c, PTR_ERR_INVALID, "max_samples_per_frame must be > 0");
+    RcCache& r = *c->rcc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    PTR_TRY(order_after_last(c, s));
+    PTR_TRY(ensure_uploaded(c, s));
+    const int w = r.width, h = r.height, st = w + 2;
+
+    // reprojectFrame (with detachFrameFromCache: the interior's sample flags)
+    ptr_rc_camera cam;
+    std::memcpy(cam.from, view->from, sizeof cam.from);
+    std::memcpy(cam.view, view->world_inv, sizeof cam.view);
+    std::memcpy(cam.proj, view->proj, sizeof cam.proj);
+    cam.width = w; cam.height = h;
+    PTR_TRY(rc_enqueue(c, &cam, r.n_items, static_cast<const double*>(r.item_hit.ptr), static_cast<double*>(r.item_age.ptr),
+                       par->age_factor, par->depth_threshold, static_cast<int32_t*>(r.item_pixel.ptr),
+                       static_cast<int32_t*>(r.pixel_element.ptr), static_cast<double*>(r.pixel_depth.ptr), s));
+    HIP_TRY(c, hipMemset2DAsync(static_cast<uint8_t*>(r.pixel_sample.ptr) + st + 1, (size_t)st, 0, (size_t)w, (size_t)h, s));
+
+    // depthCulling + fillGaps
+    ptr_rc_shade_params sp = {w, h, par->age_factor, par->interpolation_zero, par->interpolation_random, par->priority_max};
+    RcShadeArgs sa = rc_shade_args(&sp, r.n_items);
+    unsigned char* words = static_cast<unsigned char*>(r.words.ptr);
+    sa.pixel_element = static_cast<const int32_t*>(r.pixel_element.ptr); sa.pixel_depth = static_cast<const double*>(r.pixel_depth.ptr);
+    sa.item_age = static_cast<double*>(r.item_age.ptr); sa.item_rgb = static_cast<const uint32_t*>(r.item_rgb.ptr);
+    sa.pixel_rgb = static_cast<uint32_t*>(r.pixel_rgb.ptr); sa.pixel_priority = static_cast<int32_t*>(r.pixel_priority.ptr);
+    sa.hist = reinterpret_cast<uint32_t*>(words + RC_WORDS_HIST); sa.totals = reinterpret_cast<long long*>(words + RC_WORDS_TOTALS);
+    PTR_TRY(grow(c, c->rc_page, (size_t)st * (size_t)(h + 2) * sizeof(double)));
+    sa.pixel_age = static_cast<double*>(c->rc_page.ptr);
+    HIP_TRY(c, launch_rc_shade(sa, s));
+
+    // directSamples: threshold and candidates on the GPU, the running sum of the picks here
+    RcLoopArgs a = rc_loop_args(r);
+    a.priority_max = (int)par->priority_max;
+    a.age_factor = par->age_factor; a.max_samples = par->max_samples_per_frame;
+    std::memcpy(a.from, view->from, sizeof a.from);
+    std::memcpy(a.world, view->world, sizeof a.world);
+    std::memcpy(a.proj_inv, view->proj_inv, sizeof a.proj_inv);
+    HIP_TRY(c, launch_rc_candidates(a, r.temp.ptr, r.temp.bytes, s));
+    HIP_TRY(c, hipMemcpyAsync(r.host_words, words, RC_WORDS_BYTES, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    RcLoopWords lw;
+    std::memcpy(&lw, r.host_words + RC_WORDS_LOOP, sizeof lw);
+    long long totals[3];
+    std::memcpy(totals, r.host_words + RC_WORDS_TOTALS, sizeof totals);
+    const double rf = lw.samples / par->max_samples_per_frame;          // :708
+    const double n_cand = (double)lw.candidates;
+    int n_picks = 0;
+    if (lw.candidates > 0) {
+        if (!(rf > 0) || n_cand / rf > 4.0e9)
+            return fail(c, PTR_ERR_INVALID, "request factor %g with %d candidates: the reference's pick loop (Driver.js:795-822) would "
+                                            "not end", rf, lw.candidates);
+        double index = 0, last_i = -1;                                  // :795-822; lastI === null is the -1 here
+        while (index < n_cand) {
+            const double i = js_round(index);
+            if (i != last_i && i < n_cand) r.host_picks[n_picks++] = (int32_t)i;
+            last_i = i;
+            index += rf;
+        }
+    }
+    a.n_picks = n_picks;
+    if (n_picks > 0) {
+        HIP_TRY(c, hipMemcpyAsync(r.picks.ptr, r.host_picks, (size_t)n_picks * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, launch_rc_requests(a, r.temp.ptr, r.temp.bytes, s));
+        TraceArgs t;                                                    // requestSamples: Sample.doRaytracing for every request
+        std::memset(&t, 0, sizeof t);
+        t.scene = static_cast<const unsigned char*>(c->scenes.ptr);
+        t.dirs = a.dirs; t.n = n_picks; t.rc_mode = 1;
+        for (int k = 0; k < 3; k++) t.org[k] = view->from[k];
+        t.out_rgb = static_cast<double*>(r.tr_rgb.ptr); t.out_hit = static_cast<double*>(r.tr_hit.ptr);
+        HIP_TRY(c, launch_trace_batch_exact(t, s));
+    }
+    HIP_TRY(c, launch_rc_store(a, s));
+    HIP_TRY(c, hipMemcpyAsync(r.host_words + RC_WORDS_LOOP, words + RC_WORDS_LOOP, sizeof(RcLoopWords), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    std::memcpy(&lw, r.host_words + RC_WORDS_LOOP, sizeof lw);
+    out->threshold = lw.threshold < 0 ? std::nan("") : (double)lw.threshold;
+    out->request_factor = rf;
+    out->candidates = n_cand;
+    out->requests = (double)n_picks;
+    out->completeness = 100.0 * ((double)totals[0] / ((double)w * (double)h));        // :676
+    out->total_priority = (double)totals[1];
+    out->total_priority_increment = (double)totals[2];
+    out->cache_usage = (double)lw.used / (double)r.n_items;
+    return PTR_OK;
+}
+
+int ptr_rc_get_frames(ptr_ctx* c, uint32_t* color_frame, uint32_t* reprojection_frame, uint32_t* priority_frame, uint32_t* sampling_frame)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    PTR_TRY(rc_cache_ready(c, true));
+    RcCache& r = *c->rcc;
+    uint32_t* host[4] = {color_frame, reprojection_frame, priority_frame, sampling_frame};
+    if (!host[0] && !host[1] && !host[2] && !host[3]) return PTR_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    RcLoopArgs a = rc_loop_args(r);
+    const size_t px = (size_t)r.width * (size_t)r.height;
+    for (int k = 0; k < 4; k++) a.frames[k] = host[k] ? static_cast<uint32_t*>(r.frames.ptr) + (size_t)k * px : nullptr;
+    HIP_TRY(c, launch_rc_frames(a, s));
+    for (int k = 0; k < 4; k++)
+        if (host[k]) HIP_TRY(c, hipMemcpyAsync(host[k], a.frames[k], px * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     return PTR_OK;
 }

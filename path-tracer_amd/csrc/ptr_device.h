@@ -223,6 +223,41 @@ struct RcShadeArgs {
     double* pixel_age;                       // scratch owned by the context, grid: the element's age after culling
 };
 
+// render cache frame loop on a cache that stays in HBM (ptr_kernels_rcloop.hip).  RcLoopWords is the small block of
+// device words the passes of one frame hand to each other and the host reads back; it follows the 3 x 256 histogram
+// bins and the 3 totals of the shading pass in one allocation (RC_WORDS_* offsets).
+struct RcLoopWords {
+    double  samples;                 // Driver.directSamples: priorities summed down to the threshold (Driver.js:690-706)
+    int32_t threshold;               // -1 = null (no level exceeded the budget)
+    int32_t thr_value;               // what `>= threshold` and `- threshold` see: null compares and subtracts as 0
+    int32_t candidates;              // pixels at or above the threshold
+    int32_t k_a, k_b;                // numbers of the picks whose diffusion reaches the walk's last pixel (INT_MAX: none)
+    int32_t half[3];                 // diffused amount before k_a / up to k_b / after (Driver.js:829-839 with the stale pixel)
+    int32_t n_need;                  // picks that had no cache item
+    int32_t page_next;               // page the allocator looks at next (Driver.cachePointer / 8, wrapped)
+    int32_t used;                    // cache items attached to a pixel (getCacheUsage)
+    int32_t pad;
+};
+constexpr size_t RC_WORDS_HIST = 0, RC_WORDS_TOTALS = 3 * 256 * sizeof(uint32_t),
+                 RC_WORDS_LOOP = RC_WORDS_TOTALS + 3 * sizeof(long long), RC_WORDS_BYTES = RC_WORDS_LOOP + sizeof(RcLoopWords);
+
+struct RcLoopArgs {
+    int32_t width, height, n_items, n_picks;
+    int32_t pages, priority_max, rank_lo, rank_hi;
+    double  age_factor, max_samples;
+    double  from[3], world[16], proj_inv[16];      // camera.from, matrixWorld, projectionMatrixInverse (column-major)
+    // the cache and the pixel grid
+    int32_t* item_pixel; double* item_hit; double* item_age; uint32_t* item_rgb;
+    int32_t* pixel_element; uint32_t* pixel_rgb; int32_t* pixel_priority; uint8_t* pixel_sample;
+    const uint32_t* hist; RcLoopWords* words;
+    // this frame's requests
+    int32_t* cand;                   // candidate pixels in walk order
+    const int32_t* pick_index;       // which candidates are requested
+    int32_t *pick_item, *need, *rank;
+    double* dirs; const double* tr_rgb; const double* tr_hit;
+    uint32_t* frames[4];             // colour, reprojection, priority, sampling (nullable), width * height each
+};
+
 // multi-GPU gather, copy step on the root (ptr_kernels_gather.hip); device pointers
 struct GatherArgs {
     const uint32_t* src;             // one part's rows, n_frames frames, src_frame_stride_px apart

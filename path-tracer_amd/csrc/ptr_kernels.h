@@ -27,6 +27,14 @@ hipError_t launch_rc_shade(const RcShadeArgs& a, hipStream_t s);
 size_t rc_sort_temp_bytes(int n_items, int width, int height);
 hipError_t launch_rc_reproject(const RcArgs& a, void* sort_temp, size_t sort_temp_bytes, hipStream_t s);
 
+// render cache frame loop on a resident cache (ptr_kernels_rcloop.hip): threshold + candidate walk; picks, diffusion,
+// allocator, ray directions; results into the cache + ageing; the four frames
+size_t rc_loop_temp_bytes(int width, int height);
+hipError_t launch_rc_candidates(const RcLoopArgs& a, void* temp, size_t temp_bytes, hipStream_t s);
+hipError_t launch_rc_requests(const RcLoopArgs& a, void* temp, size_t temp_bytes, hipStream_t s);
+hipError_t launch_rc_store(const RcLoopArgs& a, hipStream_t s);
+hipError_t launch_rc_frames(const RcLoopArgs& a, hipStream_t s);
+
 // multi-GPU gather: one part's compact rows -> their places in the whole frames (ptr_kernels_gather.hip)
 hipError_t launch_gather_rows(const GatherArgs& a, hipStream_t s);
 

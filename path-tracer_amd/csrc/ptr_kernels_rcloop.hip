@@ -1,0 +1,282 @@
+// ptr_kernels_rcloop.hip — what the render cache's frame loop (rendercache-js/src/Driver.js:95-115) does between the
+// reprojection / shading passes (ptr_kernels_rc.hip) and the trace of the requested samples, on a cache and a pixel grid
+// that stay in HBM:
+//   Driver.directSamples (:682-827)   threshold over the three priority histograms, the serpentine candidate walk,
+//                                     the picks at a fixed stride, the error diffusion of distributeExceedingPriority
+//                                     (:829-839) with the stale pixel it is handed (:813-814)
+//   Driver.addRequest / allocCacheItem (:252-326)   the paged allocator: 8 items per page, first empty one or the oldest
+//   Driver.requestSamples (:842-863)  ray directions (Camera.computeDirToXY, Camera.js:39-50), results into the cache
+//   Driver.age (:936-942), getCacheUsage, the four frame getters (:960-1046)
+// The reference does all of this sequentially; the order only matters in three places, and each has a parallel form
+// that gives the same state:
+//   * the candidate list is a stable compaction of the pixels in walk order (hipCUB select over a walk-order iterator);
+//   * the picks are `Math.round` of a running float64 sum: the host adds it up (130 k additions per 1080p frame) and
+//     sends the candidate numbers down;
+//   * the diffused amount depends on the priority of ONE pixel, the last of the walk, which only two picks can change
+//     (its upper and its inner neighbour): three amounts, computed by one lane, cover every pick;
+//   * the allocator hands the k-th request that needs an item the k-th page after the pointer: an exclusive sum of the
+//     need flags gives k, every page is then looked at by one lane (launches of at most `pages` requests each, so that a
+//     page is never looked at twice in one launch).
+// All of it is integer / byte / float64 work on a few words per request; nothing here is near a roofline of its own.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <climits>
+
+#include "ptr_device.h"
+#include "ptr_kernels.h"
+
+namespace ptr {
+
+namespace {
+
+__device__ __forceinline__ int rc_last_pixel(const RcLoopArgs& a)      // where the walk ends: row `height`
+{
+    return a.height * (a.width + 2) + ((a.height & 1) ? 1 : a.width);
+}
+
+// Driver.js:690-706.  `samples === null` only for the first level; a budget that is never exceeded leaves threshold null.
+__global__ void rc_threshold_kernel(RcLoopArgs a)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    double samples = 0;
+    bool first = true;
+    int threshold = -1;
+    for (int i = a.priority_max; i >= 0; i--) {
+        double test = (double)a.hist[256 + i] + (double)a.hist[i] + (double)a.hist[512 + i];    // URGENT + INTERPOLATED + SAMPLED
+        if (first) { samples = test; test = 0; first = false; }
+        if (samples + test > a.max_samples) { threshold = i; samples += test; break; }
+        samples += test;
+    }
+    RcLoopWords& w = *a.words;
+    w.samples = samples;
+    w.threshold = threshold;
+    w.thr_value = threshold < 0 ? 0 : threshold;
+    w.candidates = 0;
+    w.k_a = INT_MAX; w.k_b = INT_MAX;
+    w.half[0] = w.half[1] = w.half[2] = -1;
+    w.n_need = 0;
+    w.used = 0;
+}
+
+// k-th pixel of the walk (Driver.js:713-760): rows 1..height, even rows left to right, odd rows right to left
+struct WalkPixel {
+    int width;
+    __host__ __device__ int operator()(int k) const
+    {
+        const int y = k / width + 1, j = k - (y - 1) * width;
+        return y * (width + 2) + ((y & 1) ? width - j : 1 + j);
+    }
+};
+
+struct AtThreshold {
+    const int32_t* priority;
+    const RcLoopWords* words;
+    __device__ bool operator()(int p) const { return priority[p] >= words->thr_value; }
+};
+
+__global__ void __launch_bounds__(256) rc_pick_kernel(RcLoopArgs a)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.n_picks) return;
+    const int st = a.width + 2, p = a.cand[a.pick_index[k]];
+    a.pixel_sample[p] = 1;                                      // addRequest (:312)
+    a.need[k] = a.pixel_element[p] < 0 ? 1 : 0;
+    const int last = rc_last_pixel(a), dx_last = (a.height & 1) ? -1 : 1;
+    if (p == last - st) a.words->k_a = k;                       // its lower neighbour is the walk's last pixel
+    if (p == last - dx_last) a.words->k_b = k;                  // its neighbour in walk direction is
+}
+
+// the three diffused amounts and the number of requests without an item; runs after the sum of the need flags
+__global__ void rc_amounts_kernel(RcLoopArgs a)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    RcLoopWords& w = *a.words;
+    int pr = a.pixel_priority[rc_last_pixel(a)];
+    const int thr = w.thr_value;
+    const int h0 = (pr - thr) >> 1;                             // Math.floor((priority - threshold) / 2.0), integers
+    if (w.k_a != INT_MAX && h0 >= 0) pr += h0;
+    const int h1 = (pr - thr) >> 1;
+    if (w.k_b != INT_MAX && h1 >= 0) pr += h1;
+    const int h2 = (pr - thr) >> 1;
+    w.half[0] = h0; w.half[1] = h1; w.half[2] = h2;
+    w.n_need = a.n_picks > 0 ? a.rank[a.n_picks - 1] + a.need[a.n_picks - 1] : 0;
+}
+
+__global__ void __launch_bounds__(256) rc_diffuse_kernel(RcLoopArgs a)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.n_picks) return;
+    const RcLoopWords& w = *a.words;
+    const int st = a.width + 2, p = a.cand[a.pick_index[k]];
+    const int half = w.half[k > w.k_b ? 2 : k > w.k_a ? 1 : 0];
+    if (half < 0) return;                                       // :831
+    const int dx = ((p / st) & 1) ? -1 : 1;
+    atomicAdd(&a.pixel_priority[p + dx], half);
+    atomicAdd(&a.pixel_priority[p + st], half);
+}
+
+// Driver.allocCacheItem (:252-305) for the requests whose number among the needy ones is in [rank_lo, rank_hi)
+__global__ void __launch_bounds__(256) rc_alloc_kernel(RcLoopArgs a)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.n_picks || !a.need[k]) return;
+    const int r = a.rank[k];
+    if (r < a.rank_lo || r >= a.rank_hi) return;
+    const int p = a.cand[a.pick_index[k]];
+    const int base = (int)(((long long)a.words->page_next + r) % a.pages) * 8;
+    int take = -1, oldest = -1;
+    double max_age = -1;
+    for (int i = base; i < base + 8; i++) {
+        if (a.item_pixel[i] < 0) { take = i; break; }           // an empty item: take it
+        const double age = a.item_age[i];
+        if (age > max_age) { max_age = age; oldest = i; }
+    }
+    if (take < 0) {
+        if (oldest < 0) return;                                 // (no attached item is younger than 0; the reference would store at index -1)
+        take = oldest;                                          // Sample.clear(): the pixel that had it keeps pointing at it
+        a.item_hit[3 * (size_t)take] = __builtin_nan("");
+        a.item_age[take] = -1;
+        a.item_rgb[take] = 0u;
+    }
+    a.item_pixel[take] = p;
+    a.pixel_element[p] = take;
+}
+
+// Sample.doRaytracing's direction (Camera.computeDirToXY, Camera.js:39-50, THREE.Raycaster.setFromCamera underneath)
+__global__ void __launch_bounds__(256) rc_dirs_kernel(RcLoopArgs a)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.n_picks) return;
+    if (k == 0) a.words->page_next = (int)(((long long)a.words->page_next + a.words->n_need) % a.pages);
+    const int st = a.width + 2, p = a.cand[a.pick_index[k]];
+    const int it = a.pixel_element[p], pp = it >= 0 ? a.item_pixel[it] : -1;
+    double vx = 0, vy = 0, vz = -1;
+    if (pp >= 0) {
+        const int x = pp % st, y = pp / st;
+        vx = ((double)x / (double)a.width) * 2 - 1; vy = ((double)y / (double)a.height) * 2 - 1; vz = 0.5;
+#pragma unroll
+        for (int m = 0; m < 2; m++) {                           // Vector3.applyMatrix4: projectionMatrixInverse, then matrixWorld
+            const double* e = m == 0 ? a.proj_inv : a.world;
+            const double w = 1 / (e[3] * vx + e[7] * vy + e[11] * vz + e[15]);
+            const double nx = (e[0] * vx + e[4] * vy + e[8] * vz + e[12]) * w;
+            const double ny = (e[1] * vx + e[5] * vy + e[9] * vz + e[13]) * w;
+            const double nz = (e[2] * vx + e[6] * vy + e[10] * vz + e[14]) * w;
+            vx = nx; vy = ny; vz = nz;
+        }
+        vx -= a.world[12]; vy -= a.world[13]; vz -= a.world[14];
+        double len = __builtin_sqrt(vx * vx + vy * vy + vz * vz);
+        if (!(len != 0)) len = 1;                               // `Math.sqrt(..) || 1`: 0 and NaN are falsy
+        const double s = 1 / len;
+        vx *= s; vy *= s; vz *= s;
+        const double len2 = vx * vx + vy * vy + vz * vz;        // the cache's own Vector3.normalize (Vector3.js:23-33)
+        if (len2 > 0) { const double inv = 1 / __builtin_sqrt(len2); vx *= inv; vy *= inv; vz *= inv; }
+    }
+    a.pick_item[k] = pp >= 0 ? it : -1;                         // requestSamples only traces items that have a pixel
+    a.dirs[3 * (size_t)k] = vx; a.dirs[3 * (size_t)k + 1] = vy; a.dirs[3 * (size_t)k + 2] = vz;
+}
+
+// Driver.requestSamples (:842-863): the traced colour as bytes, the hit point, and the colour of the item's pixel.
+// An item requested twice (it was taken from a pixel requested earlier in the frame) gets the same values twice.
+__global__ void __launch_bounds__(256) rc_store_kernel(RcLoopArgs a)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.n_picks) return;
+    const int it = a.pick_item[k];
+    if (it < 0) return;
+    uint32_t v = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        v |= (js_to_uint32(js_round(js_min1(a.tr_rgb[3 * (size_t)k + c]) * 255.0)) & 255u) << (8 * c);
+        a.item_hit[3 * (size_t)it + c] = a.tr_hit[3 * (size_t)k + c];
+    }
+    a.item_rgb[it] = v;
+    a.pixel_rgb[a.item_pixel[it]] = v;
+}
+
+// age(ageFactor, cache) (:113, :936-942) and getCacheUsage's count
+__global__ void __launch_bounds__(256) rc_age_kernel(RcLoopArgs a)
+{
+    int used = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n_items; i += gridDim.x * blockDim.x) {
+        a.item_age[i] += a.age_factor;
+        used += a.item_pixel[i] >= 0 ? 1 : 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) used += __shfl_xor(used, off, 64);
+    if ((threadIdx.x & 63) == 0 && used) atomicAdd(&a.words->used, used);
+}
+
+// getColorFrame / getReprojectionFrame / getPriorityFrame / getSamplingFrame (:960-1046) from the live state, rows bottom-up
+__global__ void __launch_bounds__(256) rc_frames_kernel(RcLoopArgs a)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x + 1, y = blockIdx.y + 1;
+    if (x > a.width) return;
+    const int p = y * (a.width + 2) + x;
+    const size_t at = (size_t)(a.height - y) * a.width + (x - 1);
+    const uint32_t alpha = 255u << 24;
+    if (a.frames[0]) a.frames[0][at] = alpha | a.pixel_rgb[p];
+    if (a.frames[1]) { const int e = a.pixel_element[p]; a.frames[1][at] = alpha | (e >= 0 ? a.item_rgb[e] : 0u); }
+    if (a.frames[2]) { const uint32_t v = (uint32_t)a.pixel_priority[p]; a.frames[2][at] = alpha | (v << 16) | (v << 8) | v; }
+    if (a.frames[3]) a.frames[3][at] = a.pixel_sample[p] ? 0xffffffffu : 0xff000000u;
+}
+
+using WalkIterator = hipcub::TransformInputIterator<int, WalkPixel, hipcub::CountingInputIterator<int>>;
+
+inline dim3 blocks_for(int n) { return dim3((unsigned)((n + 255) / 256)); }
+
+}  // namespace
+
+size_t rc_loop_temp_bytes(int width, int height)
+{
+    const int px = width * height;
+    size_t a = 0, b = 0;
+    WalkIterator walk(hipcub::CountingInputIterator<int>(0), WalkPixel{width});
+    if (hipcub::DeviceSelect::If(nullptr, a, walk, (int32_t*)nullptr, (int32_t*)nullptr, px, AtThreshold{nullptr, nullptr}) != hipSuccess)
+        return 0;
+    if (hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const int32_t*)nullptr, (int32_t*)nullptr, px) != hipSuccess) return 0;
+    return a > b ? a : b;
+}
+
+hipError_t launch_rc_candidates(const RcLoopArgs& a, void* temp, size_t temp_bytes, hipStream_t s)
+{
+    hipLaunchKernelGGL(rc_threshold_kernel, dim3(1), dim3(64), 0, s, a);
+    WalkIterator walk(hipcub::CountingInputIterator<int>(0), WalkPixel{a.width});
+    return hipcub::DeviceSelect::If(temp, temp_bytes, walk, a.cand, &a.words->candidates, a.width * a.height,
+                                    AtThreshold{a.pixel_priority, a.words}, s);
+}
+
+hipError_t launch_rc_requests(const RcLoopArgs& a, void* temp, size_t temp_bytes, hipStream_t s)
+{
+    if (a.n_picks <= 0) return hipSuccess;
+    const dim3 grid = blocks_for(a.n_picks);
+    hipLaunchKernelGGL(rc_pick_kernel, grid, dim3(256), 0, s, a);
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, a.need, a.rank, a.n_picks, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rc_amounts_kernel, dim3(1), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(rc_diffuse_kernel, grid, dim3(256), 0, s, a);
+    for (long long lo = 0; lo < a.n_picks; lo += a.pages) {     // one launch unless a frame requests more items than there are pages
+        RcLoopArgs b = a;
+        b.rank_lo = (int)lo;
+        b.rank_hi = (int)(lo + a.pages < (long long)a.n_picks ? lo + a.pages : (long long)a.n_picks);
+        hipLaunchKernelGGL(rc_alloc_kernel, grid, dim3(256), 0, s, b);
+    }
+    hipLaunchKernelGGL(rc_dirs_kernel, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_rc_store(const RcLoopArgs& a, hipStream_t s)
+{
+    if (a.n_picks > 0) hipLaunchKernelGGL(rc_store_kernel, blocks_for(a.n_picks), dim3(256), 0, s, a);
+    const int blocks = (a.n_items + 255) / 256;
+    hipLaunchKernelGGL(rc_age_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_rc_frames(const RcLoopArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(rc_frames_kernel, dim3((unsigned)((a.width + 255) / 256), (unsigned)a.height), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace ptr

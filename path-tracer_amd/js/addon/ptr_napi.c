@@ -20,6 +20,8 @@
  *                                                                            ptr_trace_batch_f64
  *   commInitAll([h...])                                                      ptr_comm_init_all
  *   renderMulti([h...], w, height, flags[, maxDepth, spp, seed]) -> ArrayBuffer   ptr_render_multi
+ *   rcCacheCreate / rcCacheUpload / rcCacheDownload / rcNextFrame / rcGetFrame / rcCacheDestroy: the render cache's frame
+ *        loop on a cache resident on the GPU                                  ptr_rc_cache_*, ptr_rc_next_frame, ptr_rc_get_frames
  *   stats(h) -> { primary, hits, shadowRays, exitTca, exitD2, exitHit, retraced, reshaded }   ptr_get_stats
  */
 #include <node_api.h>
@@ -565,6 +567,144 @@ static napi_value js_rc_shade(napi_env env, napi_callback_info info)
     return out;
 }
 
+/* ---- the render cache's frame loop on a cache that stays on the GPU (ptr_rc_cache_*, ptr_rc_next_frame) ------------ */
+
+/* rcCacheCreate(h, width, height, nItems) */
+static napi_value js_rc_cache_create(napi_env env, napi_callback_info info)
+{
+    napi_value argv[4];
+    int32_t w, h, n;
+    if (!get_args(env, info, 4, argv)) return NULL;
+    ptr_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx || !get_i32(env, argv[1], &w) || !get_i32(env, argv[2], &h) || !get_i32(env, argv[3], &n)) return NULL;
+    int rc = ptr_rc_cache_create(ctx, w, h, n);
+    if (rc != PTR_OK) return throw_ptr(env, ctx, rc);
+    return NULL;
+}
+
+static napi_value js_rc_cache_destroy(napi_env env, napi_callback_info info)
+{
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    ptr_ctx *ctx = get_ctx(env, argv[0]);
+    if (ctx) ptr_rc_cache_destroy(ctx);
+    return NULL;
+}
+
+/* the nine state arrays of rcCacheUpload / rcCacheDownload, argv[1..9]: Int32Array itemPixel(n), Float64Array itemHit(3n),
+ * Float64Array itemAge(n), Uint32Array itemRgb(n), Int32Array pixelElement(cells), Float64Array pixelDepth(cells),
+ * Uint32Array pixelRgb(cells), Int32Array pixelPriority(cells), Uint8Array pixelSample(cells) */
+static int get_rc_state(napi_env env, ptr_ctx *ctx, napi_value *argv, void **d)
+{
+    int w, h, n;
+    int rc = ptr_rc_cache_shape(ctx, &w, &h, &n);
+    if (rc != PTR_OK) { throw_ptr(env, ctx, rc); return 0; }
+    const size_t cells = (size_t)(w + 2) * (size_t)(h + 2);
+    static const napi_typedarray_type types[9] = { napi_int32_array, napi_float64_array, napi_float64_array, napi_uint32_array,
+                                                   napi_int32_array, napi_float64_array, napi_uint32_array, napi_int32_array, napi_uint8_array };
+    size_t len[9];
+    for (int k = 0; k < 9; k++)
+        if (!get_typed(env, argv[1 + k], types[k], &d[k], &len[k])) return 0;
+    if (len[0] != (size_t)n || len[1] != 3 * len[0] || len[2] != len[0] || len[3] != len[0] || len[4] != cells || len[5] != cells ||
+        len[6] != cells || len[7] != cells || len[8] != cells) {
+        napi_throw_range_error(env, "PTR_ERR_INVALID", "item arrays need n (hits 3n) entries, pixel arrays (w+2)*(h+2)");
+        return 0;
+    }
+    return 1;
+}
+
+/* rcCacheUpload(h, <nine arrays>, cachePointer): the lengths must be those the cache was created with (the library
+ * reads n_items and (w+2)*(h+2) entries): checked against ptr_rc_cache_shape */
+static napi_value js_rc_cache_upload(napi_env env, napi_callback_info info)
+{
+    napi_value argv[11];
+    void *d[9];
+    double cp;
+    if (!get_args(env, info, 11, argv)) return NULL;
+    ptr_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx || !get_rc_state(env, ctx, argv, d)) return NULL;
+    if (napi_get_value_double(env, argv[10], &cp) != napi_ok) { napi_throw_type_error(env, NULL, "cachePointer must be a number"); return NULL; }
+    int rc = ptr_rc_cache_upload(ctx, (const int32_t *)d[0], (const double *)d[1], (const double *)d[2], (const uint32_t *)d[3],
+                                 (const int32_t *)d[4], (const double *)d[5], (const uint32_t *)d[6], (const int32_t *)d[7],
+                                 (const uint8_t *)d[8], (int64_t)cp);
+    if (rc != PTR_OK) return throw_ptr(env, ctx, rc);
+    return NULL;
+}
+
+/* rcCacheDownload(h, <nine arrays, written in place>) -> cachePointer */
+static napi_value js_rc_cache_download(napi_env env, napi_callback_info info)
+{
+    napi_value argv[10], out;
+    void *d[9];
+    int64_t cp = 0;
+    if (!get_args(env, info, 10, argv)) return NULL;
+    ptr_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx || !get_rc_state(env, ctx, argv, d)) return NULL;
+    int rc = ptr_rc_cache_download(ctx, (int32_t *)d[0], (double *)d[1], (double *)d[2], (uint32_t *)d[3], (int32_t *)d[4],
+                                   (double *)d[5], (uint32_t *)d[6], (int32_t *)d[7], (uint8_t *)d[8], &cp);
+    if (rc != PTR_OK) return throw_ptr(env, ctx, rc);
+    NAPI_TRY(env, napi_create_double(env, (double)cp, &out));
+    return out;
+}
+
+/* rcNextFrame(h, Float64Array view(67: from[3] matrixWorld[16] matrixWorldInverse[16] projectionMatrix[16]
+ *             projectionMatrixInverse[16]), Float64Array params(6: ageFactor, depthThreshold, interpolationZero,
+ *             interpolationRandom, priorityMax, maximumSamplesPerFrame))
+ *   -> Float64Array(8: threshold (NaN = null), requestFactor, candidates, requests, completeness, totalPriority,
+ *                      increment of Driver.totalPriority, cache usage) */
+static napi_value js_rc_next_frame(napi_env env, napi_callback_info info)
+{
+    napi_value argv[3], ab, out;
+    double *v, *p; size_t nv, np;
+    void *data;
+    if (!get_args(env, info, 3, argv)) return NULL;
+    ptr_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx || !get_f64_array(env, argv[1], &v, &nv) || !get_f64_array(env, argv[2], &p, &np)) return NULL;
+    if (!v || nv != 67 || !p || np != 6) {
+        napi_throw_range_error(env, "PTR_ERR_INVALID", "view needs 67 numbers, params 6");
+        return NULL;
+    }
+    ptr_rc_view view;
+    ptr_rc_loop_params par = { p[0], p[1], p[2], p[3], p[4], p[5] };
+    ptr_rc_frame_stats st;
+    memcpy(view.from, v, 3 * sizeof(double));
+    memcpy(view.world, v + 3, 16 * sizeof(double));
+    memcpy(view.world_inv, v + 19, 16 * sizeof(double));
+    memcpy(view.proj, v + 35, 16 * sizeof(double));
+    memcpy(view.proj_inv, v + 51, 16 * sizeof(double));
+    int rc = ptr_rc_next_frame(ctx, &view, &par, &st);
+    if (rc != PTR_OK) return throw_ptr(env, ctx, rc);
+    NAPI_TRY(env, napi_create_arraybuffer(env, 8 * sizeof(double), &data, &ab));
+    const double vals[8] = { st.threshold, st.request_factor, st.candidates, st.requests, st.completeness, st.total_priority,
+                             st.total_priority_increment, st.cache_usage };
+    memcpy(data, vals, sizeof vals);
+    NAPI_TRY(env, napi_create_typedarray(env, napi_float64_array, 8, ab, 0, &out));
+    return out;
+}
+
+/* rcGetFrame(h, which (0 colour, 1 reprojection, 2 priority, 3 sampling), Uint32Array out(w*h)) */
+static napi_value js_rc_get_frame(napi_env env, napi_callback_info info)
+{
+    napi_value argv[3];
+    int32_t which;
+    void *out; size_t n;
+    if (!get_args(env, info, 3, argv)) return NULL;
+    ptr_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx || !get_i32(env, argv[1], &which) || !get_typed(env, argv[2], napi_uint32_array, &out, &n)) return NULL;
+    int w, h, items;
+    int rc = ptr_rc_cache_shape(ctx, &w, &h, &items);
+    if (rc != PTR_OK) return throw_ptr(env, ctx, rc);
+    if (which < 0 || which > 3 || n != (size_t)w * (size_t)h) {
+        napi_throw_range_error(env, "PTR_ERR_INVALID", "which must be 0..3 and out hold width * height words");
+        return NULL;
+    }
+    uint32_t *f[4] = { NULL, NULL, NULL, NULL };
+    f[which] = (uint32_t *)out;
+    rc = ptr_rc_get_frames(ctx, f[0], f[1], f[2], f[3]);
+    if (rc != PTR_OK) return throw_ptr(env, ctx, rc);
+    return NULL;
+}
+
 /* handles: a JS array of renderer handles -> ptr_ctx*[] (at most 64); 0 on a bad argument (exception pending) */
 static int get_ctx_array(napi_env env, napi_value arr, ptr_ctx **out, uint32_t *n)
 {
@@ -648,6 +788,8 @@ NAPI_MODULE_INIT()
         {"setBackground", js_set_background}, {"setCamera", js_set_camera}, {"setExtension", js_set_extension}, {"render", js_render},
         {"renderAsync", js_render_async}, {"traceBatch", js_trace_batch}, {"traceSamples", js_trace_samples}, {"rcReproject", js_rc_reproject}, {"rcShade", js_rc_shade}, {"stats", js_stats},
         {"commInitAll", js_comm_init_all}, {"renderMulti", js_render_multi},
+        {"rcCacheCreate", js_rc_cache_create}, {"rcCacheDestroy", js_rc_cache_destroy}, {"rcCacheUpload", js_rc_cache_upload},
+        {"rcCacheDownload", js_rc_cache_download}, {"rcNextFrame", js_rc_next_frame}, {"rcGetFrame", js_rc_get_frame},
     };
     for (size_t k = 0; k < sizeof fns / sizeof fns[0]; k++) {
         napi_value f;

@@ -56,6 +56,10 @@ export class RcCamera {
  * getSamplingFrame, getCacheUsage, statistics.  Pixels live on the (w + 2) x (h + 2) grid of Driver.allocBuffers.
  *
  *   const drv = new RenderCacheDriver(rayTracer, new RcCamera(w, h), 16);   // rayTracer: ../RayTracer.js with a scene
+ *   const drv = new RenderCacheDriver(rayTracer, camera, 16, { resident: true });
+ *       // the cache and the pixel grid stay in HBM (ptr_rc_cache_*, ptr_rc_next_frame): per frame the camera goes down and the
+ *       // statistics come back, the host walks of this file run as GPU passes with the same results; only the first frame's
+ *       // initializeCache (Math.random) runs here.  syncToHost() brings the state back into the typed arrays below.
  *   drv.prepare(false);
  *   camera.setView(from, cam.matrixWorld.elements, ...); drv.nextFrame(k); drv.getColorFrame(rgba);
  */
@@ -63,6 +67,8 @@ export default class RenderCacheDriver {
     constructor(engine, camera, ratio, options = {}) {
         this.engine = engine; this.camera = camera;
         this.rc = new RenderCache({ device: options.device | 0 });
+        this.resident = !!options.resident;
+        this._onGpu = false;                                     // the state lives in the engine's GPU context
         this.test = false;
         this.cachePointer = 0; this.cachePageSize = 8;
         this.initialFill = 0.2;
@@ -76,7 +82,50 @@ export default class RenderCacheDriver {
                             totalPriority: 0, requestFactor: 0, threshold: 0, candidates: 0, requests: 0 };
     }
 
-    dispose() { this.rc.dispose(); }
+    dispose() {
+        if (this._onGpu && this.engine._handle) this.engine._native.rcCacheDestroy(this.engine._handle);
+        this._onGpu = false;
+        this.rc.dispose();
+    }
+
+    // ---- resident mode: the state's way to and from the GPU ----------------------------------------------------------
+    _stateArrays(priority) {
+        return [this.itemPixel, this.itemHit, this.itemAge, this.itemRgb, this.pixelElement, this.pixelDepth, this.pixelRgb,
+                priority, this.pixelSample];
+    }
+
+    _toGpu() {
+        const nat = this.engine._native, h = this.engine._handle;
+        if (!h) throw new Error('RayTracer was disposed');
+        nat.rcCacheCreate(h, this.camera.scope.x, this.camera.scope.y, this.cacheSize);
+        nat.rcCacheUpload(h, ...this._stateArrays(Int32Array.from(this.pixelPriority)), this.cachePointer);
+        this._onGpu = true;
+    }
+
+    /** resident mode: copy the cache and the pixel grid back into this object's typed arrays (the GPU copy stays in charge) */
+    syncToHost() {
+        if (!this._onGpu) return;
+        const prio = new Int32Array(this.pixelPriority.length);
+        this.cachePointer = this.engine._native.rcCacheDownload(this.engine._handle, ...this._stateArrays(prio));
+        this.pixelPriority.set(prio);
+    }
+
+    _residentFrame() {
+        const nat = this.engine._native, cam = this.camera;
+        if (!this._onGpu) this._toGpu();
+        this.engine._upload(false);                              // the scene is re-read every frame, as traceSamples does
+        const view = new Float64Array(67);
+        view.set([cam.from.x, cam.from.y, cam.from.z], 0);
+        view.set(cam.matrixWorld, 3); view.set(cam.matrixWorldInverse, 19);
+        view.set(cam.projectionMatrix, 35); view.set(cam.projectionMatrixInverse, 51);
+        const st = nat.rcNextFrame(this.engine._handle, view, Float64Array.of(this.ageFactor, this.depthThreshold, this.interpolationZero,
+                                   this.interpolationRandom, this.priorityMax, this.maximumSamplesPerFrame));
+        const s = this.statistics;
+        s.threshold = Number.isNaN(st[0]) ? null : st[0];
+        s.requestFactor = st[1]; s.candidates = st[2]; s.requests = st[3]; s.completeness = st[4]; s.totalPriority = st[5];
+        this.totalPriority += st[6];
+        this._cacheUsage = st[7];
+    }
 
     /** Driver.prepare (:81-88): buffers first, cache next, and only then the test flag (so cacheFactor stays 4) */
     prepare(isTest) {
@@ -161,8 +210,12 @@ export default class RenderCacheDriver {
     /** Driver.nextFrame (:95-115) */
     nextFrame(frameIndex) {
         if (this.test) { this.initializeCacheWithEntireFrame(); return; }
-        if (frameIndex === 0) this.initializeCache();
+        if (frameIndex === 0) {
+            if (this._onGpu) { this.syncToHost(); this._onGpu = false; }      // a restart: the cache is filled on the host again
+            this.initializeCache();
+        }
         this.frameIndex = frameIndex;
+        if (this.resident) return this._residentFrame();
         this.reprojectFrame();
         this.shadeFrame();                                      // depthCulling + fillGaps
         const requests = this.directSamples();
@@ -273,24 +326,31 @@ export default class RenderCacheDriver {
     age(amount, items) { for (let i = 0; i < items.length; i++) this.itemAge[items[i]] += amount; }     // :936-942
 
     getCacheUsage() {
+        if (this._onGpu) return this._cacheUsage;
         let used = 0;
         for (let i = 0; i < this.cacheSize; i++) if (this.itemPixel[i] >= 0) used++;
         return used / this.cacheSize;
     }
 
     // ---- frames (:960-1046): rows bottom-up, RGBA8 --------------------------------------------------------------------
+    _gpuFrame(which, buf) {
+        const out = buf instanceof Uint32Array ? buf : new Uint32Array(this.camera.scope.x * this.camera.scope.y);
+        this.engine._native.rcGetFrame(this.engine._handle, which, out);
+        if (out !== buf) for (let k = 0; k < out.length; k++) buf[k] = out[k];
+        return buf;
+    }
     _frame(buf, f) {
         const w = this.camera.scope.x, h = this.camera.scope.y, st = this.stride;
         let k = 0;
         for (let y = h - 1; y >= 0; y--) for (let x = 0; x < w; x++, k++) buf[k] = f((y + 1) * st + x + 1);
         return buf;
     }
-    getColorFrame(buf) { return this._frame(buf, p => ((255 << 24) | this.pixelRgb[p]) >>> 0); }
+    getColorFrame(buf) { return this._onGpu ? this._gpuFrame(0, buf) : this._frame(buf, p => ((255 << 24) | this.pixelRgb[p]) >>> 0); }
     getReprojectionFrame(buf) {
-        return this._frame(buf, p => ((255 << 24) | (this.pixelElement[p] >= 0 ? this.itemRgb[this.pixelElement[p]] : 0)) >>> 0);
+        return this._onGpu ? this._gpuFrame(1, buf) : this._frame(buf, p => ((255 << 24) | (this.pixelElement[p] >= 0 ? this.itemRgb[this.pixelElement[p]] : 0)) >>> 0);
     }
     getPriorityFrame(buf) {
-        return this._frame(buf, p => { const v = this.pixelPriority[p]; return ((255 << 24) | (v << 16) | (v << 8) | v) >>> 0; });
+        return this._onGpu ? this._gpuFrame(2, buf) : this._frame(buf, p => { const v = this.pixelPriority[p]; return ((255 << 24) | (v << 16) | (v << 8) | v) >>> 0; });
     }
-    getSamplingFrame(buf) { return this._frame(buf, p => (this.pixelSample[p] ? 0xffffffff : 0xff000000) >>> 0); }
+    getSamplingFrame(buf) { return this._onGpu ? this._gpuFrame(3, buf) : this._frame(buf, p => (this.pixelSample[p] ? 0xffffffff : 0xff000000) >>> 0); }
 }

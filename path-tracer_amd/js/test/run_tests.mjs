@@ -300,7 +300,8 @@ async function gpuTests() {
         }
         rc.dispose();
     });
-    test('RenderCacheDriver.nextFrame(): whole render-cache frames, bit for bit (unmodified Driver.nextFrame goldens)', () => {
+    for (const resident of [false, true])
+    test(`RenderCacheDriver.nextFrame()${resident ? ', cache resident on the GPU' : ''}: whole render-cache frames, bit for bit (unmodified Driver.nextFrame goldens)`, () => {
         // tests/golden/rc/frames_*: rendercache-js Driver.nextFrame over several frames with a moving camera and a seeded
         // Math.random (the generator is named in frames_index.json); inputs = the camera state per frame, outputs = frames + statistics
         const idx = JSON.parse(fs.readFileSync(path.join(golden, 'rc', 'frames_index.json')));
@@ -315,7 +316,7 @@ async function gpuTests() {
                 Math.random = () => { s ^= s << 13; s >>>= 0; s ^= s >>> 17; s ^= s << 5; s >>>= 0; return s / 4294967296; };
                 const rt = new RayTracer(new Vector3(...desc.background), sceneFrom(desc), undefined, { mode: 'exact' });
                 const cam = new RcCamera(m.width, m.height);
-                const drv = new RenderCacheDriver(rt, cam, m.ratio);
+                const drv = new RenderCacheDriver(rt, cam, m.ratio, { resident });
                 drv.prepare(false);
                 const px = m.width * m.height, got = new Uint32Array(px);
                 for (let k = 0; k < m.frames; k++) {
@@ -336,6 +337,55 @@ async function gpuTests() {
                     assert.ok(sameBytes(drv.getSamplingFrame(got), frames.subarray((2 * k + 1) * px, (2 * k + 2) * px)), tag + ' sampling frame');
                 }
                 drv.dispose(); rt.dispose();
+            }
+        } finally {
+            Math.random = realRandom;
+        }
+    });
+    test('RenderCacheDriver: the resident frame loop leaves the same cache, grid and frames as the host walks (odd sizes, a frame that requests every pixel, a restart)', () => {
+        // no reference output exists at these sizes: the host form of the driver (bit-identical to the reference on the goldens
+        // above) is the comparator; every array of the state is compared after every frame
+        const idx = JSON.parse(fs.readFileSync(path.join(golden, 'rc', 'frames_index.json')));
+        const desc = JSON.parse(fs.readFileSync(path.join(golden, 'rc', 'index.json'))).scenes.rc_scene2;
+        const m = idx.cases.walk_96x64, rec = f64(path.join('rc', m.file));
+        const realRandom = Math.random;
+        const arrays = ['itemPixel', 'itemHit', 'itemAge', 'itemRgb', 'pixelElement', 'pixelDepth', 'pixelRgb', 'pixelPriority', 'pixelSample'];
+        try {
+            for (const [w, h, ratio, nframes] of [[151, 97, 16, 7], [64, 33, 1, 4], [320, 200, 8, 6], [37, 2, 2, 5]]) {
+                const drvs = [false, true].map(resident => {
+                    const rt = new RayTracer(new Vector3(...desc.background), sceneFrom(desc), undefined, { mode: 'exact' });
+                    const cam = new RcCamera(w, h), drv = new RenderCacheDriver(rt, cam, ratio, { resident });
+                    drv.prepare(false);
+                    return { rt, cam, drv };
+                });
+                const px = w * h, a = new Uint32Array(px), b = new Uint32Array(px);
+                for (let k = 0; k < nframes; k++) {
+                    const frameIndex = (k === 4 && w === 151) ? 0 : k;                   // a restart in the middle of one sequence
+                    const o = (k % m.frames) * m.doubles_per_frame, tag = `${w}x${h} ratio ${ratio} frame ${k}`;
+                    for (const d of drvs) {
+                        let s = (1000 + 17 * k) >>> 0;
+                        Math.random = () => { s ^= s << 13; s >>>= 0; s ^= s >>> 17; s ^= s << 5; s >>>= 0; return s / 4294967296; };
+                        d.cam.setView(rec.subarray(o, o + 3), rec.subarray(o + 3, o + 19), rec.subarray(o + 19, o + 35),
+                                      rec.subarray(o + 35, o + 51), rec.subarray(o + 51, o + 67));
+                        d.drv.nextFrame(frameIndex);
+                    }
+                    const [host, gpu] = drvs.map(d => d.drv);
+                    assert.deepStrictEqual(gpu.statistics, host.statistics, tag + ' statistics');
+                    assert.strictEqual(gpu.getCacheUsage(), host.getCacheUsage(), tag + ' cache usage');
+                    assert.strictEqual(gpu.totalPriority, host.totalPriority, tag + ' totalPriority');
+                    for (const f of ['getColorFrame', 'getReprojectionFrame', 'getPriorityFrame', 'getSamplingFrame'])
+                        assert.ok(sameBytes(gpu[f](a), host[f](b)), `${tag} ${f}`);
+                    gpu.syncToHost();
+                    const pages = Math.floor(host.cacheSize / 8);
+                    assert.strictEqual((gpu.cachePointer / 8) % pages, (host.cachePointer / 8) % pages, tag + ' cachePointer');
+                    for (const name of arrays) {
+                        const x = gpu[name], y = host[name];
+                        let bad = -1;
+                        for (let i = 0; i < x.length && bad < 0; i++) if (!(x[i] === y[i] || (x[i] !== x[i] && y[i] !== y[i]))) bad = i;
+                        assert.strictEqual(bad, -1, `${tag} ${name}[${bad}]: ${x[bad]} !== ${y[bad]}`);
+                    }
+                }
+                for (const d of drvs) { d.drv.dispose(); d.rt.dispose(); }
             }
         } finally {
             Math.random = realRandom;

@@ -31,6 +31,8 @@ SYMBOLS = [
     "ptr_trace_batch", "ptr_trace_batch_f64", "ptr_trace_samples_f64", "ptr_rc_reproject", "ptr_rc_reproject_device", "ptr_rc_shade", "ptr_rc_shade_device", "ptr_get_stats", "ptr_get_kernel_ms",
     "ptr_comm_unique_id", "ptr_comm_init_rank", "ptr_comm_init_all", "ptr_comm_destroy",
     "ptr_gather_strips_device", "ptr_gather_strips_all", "ptr_place_strips_device", "ptr_render_multi",
+    "ptr_rc_cache_create", "ptr_rc_cache_destroy", "ptr_rc_cache_shape", "ptr_rc_cache_upload", "ptr_rc_cache_download",
+    "ptr_rc_next_frame", "ptr_rc_get_frames",
 ]
 
 
@@ -53,6 +55,27 @@ class RcCamera(C.Structure):
 class RcShadeParams(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("age_factor", C.c_double), ("interpolation_zero", C.c_double),
                 ("interpolation_random", C.c_double), ("priority_max", C.c_double)]
+
+
+class RcView(C.Structure):
+    _fields_ = [("from_", C.c_double * 3), ("world", C.c_double * 16), ("world_inv", C.c_double * 16),
+                ("proj", C.c_double * 16), ("proj_inv", C.c_double * 16)]
+
+
+class RcLoopParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("age_factor", "depth_threshold", "interpolation_zero", "interpolation_random",
+                                          "priority_max", "max_samples_per_frame")]
+
+
+class RcFrameStats(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("threshold", "request_factor", "candidates", "requests", "completeness",
+                                          "total_priority", "total_priority_increment", "cache_usage")]
+
+
+# the render cache's state as ptr_rc_cache_upload / _download order it: (name, dtype, entries per item or per grid cell)
+RC_STATE = (("item_pixel", np.int32, "n"), ("item_hit", np.float64, "3n"), ("item_age", np.float64, "n"), ("item_rgb", np.uint32, "n"),
+            ("pixel_element", np.int32, "c"), ("pixel_depth", np.float64, "c"), ("pixel_rgb", np.uint32, "c"),
+            ("pixel_priority", np.int32, "c"), ("pixel_sample", np.uint8, "c"))
 
 
 class Strips(C.Structure):
@@ -152,6 +175,14 @@ def lib():
         L.ptr_gather_strips_all.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.c_uint64, vp]
         L.ptr_place_strips_device.argtypes = [vp, C.POINTER(Strips), C.c_int, C.c_int, C.c_int, vp, C.c_uint64, vp, vp]
         L.ptr_render_multi.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(Params), C.POINTER(C.c_uint32)]
+        L.ptr_rc_cache_create.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+        L.ptr_rc_cache_destroy.argtypes = [vp]
+        L.ptr_rc_cache_destroy.restype = None
+        L.ptr_rc_cache_shape.argtypes = [vp, ip, ip, ip]
+        L.ptr_rc_cache_upload.argtypes = [vp] * 10 + [C.c_int64]
+        L.ptr_rc_cache_download.argtypes = [vp] * 10 + [C.POINTER(C.c_int64)]
+        L.ptr_rc_next_frame.argtypes = [vp, C.POINTER(RcView), C.POINTER(RcLoopParams), C.POINTER(RcFrameStats)]
+        L.ptr_rc_get_frames.argtypes = [vp, up, up, up, up]
         L.ptr_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.ptr_get_kernel_ms.argtypes = [vp, fp, fp]
         _lib = L
@@ -382,6 +413,55 @@ class Renderer:
         self._check(self._L.ptr_rc_reproject_device(self._h, C.byref(cam), n, C.c_void_p(d_hit), C.c_void_p(d_age), age_factor,
                                                     depth_threshold, C.c_void_p(d_item_pixel), C.c_void_p(d_pel),
                                                     C.c_void_p(d_pdep), C.c_void_p(stream) if stream else None))
+
+    # ---- the render cache's frame loop on a cache resident on the GPU (ptr_rc_cache_*, ptr_rc_next_frame) ----
+    def rc_cache_create(self, width, height, n_items):
+        self._check(self._L.ptr_rc_cache_create(self._h, width, height, n_items))
+        self._rc_shape = (width, height, n_items)
+
+    def rc_cache_destroy(self):
+        self._L.ptr_rc_cache_destroy(self._h)
+
+    def _rc_sizes(self):
+        w, h, n = self._rc_shape
+        return {"n": n, "3n": 3 * n, "c": (w + 2) * (h + 2)}
+
+    def rc_cache_upload(self, state, cache_pointer):
+        """state: dict of the arrays RC_STATE names (numpy, converted to the dtypes listed there)"""
+        sizes = self._rc_sizes()
+        arrs = []
+        for name, dt, size in RC_STATE:
+            a = np.ascontiguousarray(state[name], dtype=dt).reshape(-1)
+            if a.size != sizes[size]:
+                raise ValueError(f"{name} needs {sizes[size]} entries, has {a.size}")
+            arrs.append(a)
+        self._check(self._L.ptr_rc_cache_upload(self._h, *[C.c_void_p(a.ctypes.data) for a in arrs], int(cache_pointer)))
+
+    def rc_cache_download(self):
+        sizes = self._rc_sizes()
+        out = {name: np.empty(sizes[size], dtype=dt) for name, dt, size in RC_STATE}
+        cp = C.c_int64(0)
+        self._check(self._L.ptr_rc_cache_download(self._h, *[C.c_void_p(out[name].ctypes.data) for name, _, _ in RC_STATE], C.byref(cp)))
+        return out, cp.value
+
+    def rc_next_frame(self, cam_from, world, world_inv, proj, proj_inv, max_samples_per_frame, age_factor=1.0, depth_threshold=1e6,
+                      zero=20.0, rnd=5.0, pmax=255.0):
+        v = RcView()
+        v.from_[:] = [float(x) for x in cam_from]
+        for name, m in (("world", world), ("world_inv", world_inv), ("proj", proj), ("proj_inv", proj_inv)):
+            getattr(v, name)[:] = [float(x) for x in np.asarray(m, dtype=np.float64).reshape(16)]
+        p = RcLoopParams(age_factor, depth_threshold, zero, rnd, pmax, max_samples_per_frame)
+        st = RcFrameStats()
+        self._check(self._L.ptr_rc_next_frame(self._h, C.byref(v), C.byref(p), C.byref(st)))
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
+    def rc_get_frames(self, which=("color", "reprojection", "priority", "sampling")):
+        w, h, _ = self._rc_shape
+        names = ("color", "reprojection", "priority", "sampling")
+        out = {k: np.empty(w * h, dtype=np.uint32) for k in which}
+        ptrs = [out[k].ctypes.data_as(C.POINTER(C.c_uint32)) if k in out else None for k in names]
+        self._check(self._L.ptr_rc_get_frames(self._h, *ptrs))
+        return out
 
     def trace_batch(self, dirs, want_hit=False):
         dirs = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
