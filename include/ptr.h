@@ -355,6 +355,32 @@ int ptr_rc_reproject_device(ptr_ctx *ctx, const ptr_rc_camera *camera, int n_ite
                             double age_factor, double depth_threshold, void *d_item_pixel, void *d_pixel_element,
                             void *d_pixel_depth, void *stream);
 
+/* The same pass for a cache whose items are split over several GPUs in cache order (BASELINE configs[4]: "point
+ * reprojection at 2/4/8 GPUs"): rank r holds items [item_base, item_base + n_local) of the whole cache.  Results are
+ * those of Driver.reprojectFrame over the WHOLE cache: every rank ends with its own items' age and item_pixel and with
+ * the whole grid (pixel_element = index in the whole cache).  One exchange step: the ranks' local grids, 12 B per pixel.
+ *   ptr_rc_reproject_shard_device   the local pass alone: local grid into d_local_element / d_local_depth (indices in
+ *                                   the whole cache; interior only);
+ *   ptr_rc_merge_shards_device      after the caller gathered all ranks' local grids (d_all_element / d_all_depth:
+ *                                   n_ranks grids one after the other, rank order): the age of a local winner that
+ *                                   loses against another rank, pixel pointers of items an earlier rank's item hides,
+ *                                   and the whole grid.  Must follow this context's shard call (it reads the local
+ *                                   pass's scratch);
+ *   ptr_rc_reproject_multi_device   both around an ncclAllGather of the two grids on the context's communicator
+ *                                   (ptr_comm_init_rank / _all; one rank: no RCCL needed).  Collective: every rank of
+ *                                   the communicator calls it.
+ * DEVICE pointers, enqueued on `stream` (NULL = the context's stream).                                          */
+int ptr_rc_reproject_shard_device(ptr_ctx *ctx, const ptr_rc_camera *camera, int n_local, int item_base,
+                                  const void *d_hit_xyz, void *d_age, double age_factor, double depth_threshold,
+                                  void *d_item_pixel, void *d_local_element, void *d_local_depth, void *stream);
+int ptr_rc_merge_shards_device(ptr_ctx *ctx, int width, int height, int n_ranks, int rank, const void *d_all_element,
+                               const void *d_all_depth, int n_local, int item_base, void *d_age, double age_factor,
+                               double depth_threshold, void *d_item_pixel, void *d_pixel_element, void *d_pixel_depth,
+                               void *stream);
+int ptr_rc_reproject_multi_device(ptr_ctx *ctx, const ptr_rc_camera *camera, int n_local, int item_base,
+                                  const void *d_hit_xyz, void *d_age, double age_factor, double depth_threshold,
+                                  void *d_item_pixel, void *d_pixel_element, void *d_pixel_depth, void *stream);
+
 /* ---- render cache: depth culling, gap filling, frames ----------------------------------- */
 
 typedef struct ptr_rc_shade_params {

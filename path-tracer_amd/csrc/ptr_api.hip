@@ -96,6 +96,7 @@ struct ptr_ctx {
     DeviceBuffer rc_rgb, rc_prgb, rc_pprio, rc_hist, rc_frames;      // staging for ptr_rc_shade (host buffers)
     DeviceBuffer rc_page;                                            // scratch of ptr_rc_shade*: per-pixel element age
     RcCache* rcc = nullptr;                                          // ptr_rc_cache_create
+    DeviceBuffer rcm_before, rcm_local_el, rcm_local_dep, rcm_all_el, rcm_all_dep;   // ptr_rc_merge_shards_device / _multi_device
     std::vector<unsigned char> host_blocks;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // PTR_FLAG_TIMING
     int timed_kernels = 0;             // kernels bracketed by ev[] in the last timed call
@@ -704,7 +705,8 @@ void ptr_destroy(ptr_ctx* c)
     for (DeviceBuffer* b : {&c->gather_stage, &c->multi_local, &c->multi_full, &c->scenes, &c->queue, &c->words, &c->out8, &c->out32f, &c->tr_in_o,
                             &c->tr_in_d, &c->tr_rgb, &c->tr_el, &c->tr_hit, &c->tr_nrm, &c->rc_depth, &c->rc_keys,
                             &c->rc_temp, &c->rc_hit, &c->rc_age, &c->rc_item, &c->rc_pel, &c->rc_pdep, &c->rc_rgb,
-                            &c->rc_prgb, &c->rc_pprio, &c->rc_hist, &c->rc_frames, &c->rc_page})
+                            &c->rc_prgb, &c->rc_pprio, &c->rc_hist, &c->rc_frames, &c->rc_page, &c->rcm_before, &c->rcm_local_el,
+                            &c->rcm_local_dep, &c->rcm_all_el, &c->rcm_all_dep})
         if (b->ptr) (void)hipFree(b->ptr);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->last_ev) (void)hipEventDestroy(c->last_ev);
@@ -1032,7 +1034,7 @@ int rc_check(ptr_ctx* c, const ptr_rc_camera* cam, int n_items, const void* hit,
 
 // enqueue the pass on stream s; all data pointers are device memory.  Caller holds c->mu.
 int rc_enqueue(ptr_ctx* c, const ptr_rc_camera* cam, int n_items, const double* d_hit, double* d_age, double age_factor,
-               double depth_threshold, int32_t* d_item_pixel, int32_t* d_pel, double* d_pdep, hipStream_t s)
+               double depth_threshold, int32_t* d_item_pixel, int32_t* d_pel, double* d_pdep, hipStream_t s, int item_base = 0)
 {
     const size_t n = (size_t)(n_items > 0 ? n_items : 1);
     PTR_TRY(grow(c, c->rc_depth, n * sizeof(double)));
@@ -1044,7 +1046,7 @@ int rc_enqueue(ptr_ctx* c, const ptr_rc_camera* cam, int n_items, const double* 
     std::memcpy(a.from, cam->from, sizeof a.from);
     std::memcpy(a.view, cam->view, sizeof a.view);
     std::memcpy(a.proj, cam->proj, sizeof a.proj);
-    a.width = cam->width; a.height = cam->height; a.n_items = n_items;
+    a.width = cam->width; a.height = cam->height; a.n_items = n_items; a.item_base = item_base;
     a.age_factor = age_factor; a.depth_threshold = depth_threshold;
     a.hit_xyz = d_hit; a.age = d_age; a.item_pixel = d_item_pixel; a.pixel_element = d_pel; a.pixel_depth = d_pdep;
     a.item_depth = static_cast<double*>(c->rc_depth.ptr);
@@ -1514,6 +1516,7 @@ struct Rccl {
     int (*CommDestroy)(void*) = nullptr;
     int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
@@ -1521,6 +1524,7 @@ struct Rccl {
     char why[256] = "";
 };
 constexpr int RCCL_UINT32 = 3;      // ncclUint32 (rccl.h: ncclInt8 0, ncclUint8 1, ncclInt32 2, ncclUint32 3)
+constexpr int RCCL_INT32 = 2, RCCL_FLOAT64 = 8;
 
 Rccl& rccl()
 {
@@ -1538,6 +1542,7 @@ Rccl& rccl()
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
         r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
         r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
         r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
         r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
@@ -1653,6 +1658,107 @@ int ptr_comm_destroy(ptr_ctx* c)
     }
     c->comm_n = 0; c->comm_rank = 0;
     return PTR_OK;
+}
+
+// ---- reprojection of a cache split over several GPUs ---------------------------------------------------------------
+extern "C++" {
+namespace {
+int rc_shard_check(ptr_ctx* c, int n_local, int item_base)
+{
+    if (n_local < 0 || item_base < 0 || (long long)item_base + n_local >= (1ll << 31))
+        return fail(c, PTR_ERR_INVALID, "bad shard: %d items from %d", n_local, item_base);
+    return PTR_OK;
+}
+
+int rc_merge_enqueue(ptr_ctx* c, int width, int height, int n_ranks, int rank, const void* d_all_el, const void* d_all_dep, int n_local,
+                     int item_base, void* d_age, double age_factor, double depth_threshold, void* d_item_pixel, void* d_pel, void* d_pdep,
+                     hipStream_t s)
+{
+    const size_t cells = (size_t)(width + 2) * (size_t)(height + 2);
+    PTR_TRY(grow(c, c->rcm_before, cells * sizeof(double)));
+    if (n_local > 0 && c->rc_depth.bytes < (size_t)n_local * sizeof(double))
+        return fail(c, PTR_ERR_INVALID, "merge: no local pass of %d items ran on this context (ptr_rc_reproject_shard_device first)", n_local);
+    RcMergeArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.width = width; a.height = height; a.n_items = n_local; a.item_base = item_base; a.n_ranks = n_ranks; a.rank = rank;
+    a.age_factor = age_factor; a.depth_threshold = depth_threshold;
+    a.all_depth = static_cast<const double*>(d_all_dep); a.all_element = static_cast<const int32_t*>(d_all_el);
+    a.age = static_cast<double*>(d_age); a.item_pixel = static_cast<int32_t*>(d_item_pixel);
+    a.item_depth = static_cast<const double*>(c->rc_depth.ptr);
+    a.pixel_element = static_cast<int32_t*>(d_pel); a.pixel_depth = static_cast<double*>(d_pdep);
+    a.before = static_cast<double*>(c->rcm_before.ptr);
+    HIP_TRY(c, launch_rc_merge(a, s));
+    return PTR_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+int ptr_rc_reproject_shard_device(ptr_ctx* c, const ptr_rc_camera* cam, int n_local, int item_base, const void* d_hit_xyz, void* d_age,
+                                  double age_factor, double depth_threshold, void* d_item_pixel, void* d_local_element,
+                                  void* d_local_depth, void* stream)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    PTR_TRY(rc_check(c, cam, n_local, d_hit_xyz, d_age, d_item_pixel, d_local_element, d_local_depth));
+    PTR_TRY(rc_shard_check(c, n_local, item_base));
+    HIP_TRY(c, hipSetDevice(c->device));
+    return rc_enqueue(c, cam, n_local, static_cast<const double*>(d_hit_xyz), static_cast<double*>(d_age), age_factor, depth_threshold,
+                      static_cast<int32_t*>(d_item_pixel), static_cast<int32_t*>(d_local_element), static_cast<double*>(d_local_depth),
+                      stream ? static_cast<hipStream_t>(stream) : c->stream, item_base);
+}
+
+int ptr_rc_merge_shards_device(ptr_ctx* c, int width, int height, int n_ranks, int rank, const void* d_all_element, const void* d_all_depth,
+                               int n_local, int item_base, void* d_age, double age_factor, double depth_threshold, void* d_item_pixel,
+                               void* d_pixel_element, void* d_pixel_depth, void* stream)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (width < 1 || height < 1 || (long long)(width + 2) * (height + 2) >= (1ll << 31))
+        return fail(c, PTR_ERR_INVALID, "bad frame size %d x %d", width, height);
+    if (n_ranks < 1 || n_ranks > 64 || rank < 0 || rank >= n_ranks) return fail(c, PTR_ERR_INVALID, "merge: rank %d of %d", rank, n_ranks);
+    if (!d_all_element || !d_all_depth || !d_pixel_element || !d_pixel_depth || (n_local > 0 && (!d_age || !d_item_pixel)))
+        return fail(c, PTR_ERR_INVALID, "a required buffer is NULL");
+    PTR_TRY(rc_shard_check(c, n_local, item_base));
+    HIP_TRY(c, hipSetDevice(c->device));
+    return rc_merge_enqueue(c, width, height, n_ranks, rank, d_all_element, d_all_depth, n_local, item_base, d_age, age_factor,
+                            depth_threshold, d_item_pixel, d_pixel_element, d_pixel_depth, stream ? static_cast<hipStream_t>(stream) : c->stream);
+}
+
+int ptr_rc_reproject_multi_device(ptr_ctx* c, const ptr_rc_camera* cam, int n_local, int item_base, const void* d_hit_xyz, void* d_age,
+                                  double age_factor, double depth_threshold, void* d_item_pixel, void* d_pixel_element,
+                                  void* d_pixel_depth, void* stream)
+{
+    if (!c) return PTR_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (c->comm_n < 1) return fail(c, PTR_ERR_INVALID, "the context belongs to no communicator (ptr_comm_init_rank / _all)");
+    PTR_TRY(rc_check(c, cam, n_local, d_hit_xyz, d_age, d_item_pixel, d_pixel_element, d_pixel_depth));
+    PTR_TRY(rc_shard_check(c, n_local, item_base));
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    const int n = c->comm_n, me = c->comm_rank;
+    const size_t cells = (size_t)(cam->width + 2) * (size_t)(cam->height + 2);
+    PTR_TRY(grow(c, c->rcm_all_el, (size_t)n * cells * sizeof(int32_t)));
+    PTR_TRY(grow(c, c->rcm_all_dep, (size_t)n * cells * sizeof(double)));
+    int32_t* all_el = static_cast<int32_t*>(c->rcm_all_el.ptr);
+    double* all_dep = static_cast<double*>(c->rcm_all_dep.ptr);
+    // the local pass writes straight into this rank's place of the gathered grids when it is alone; otherwise into a
+    // buffer of its own (ncclAllGather's send buffer must not lie inside the receive buffer except at its own offset)
+    int32_t* loc_el = all_el + (size_t)me * cells;
+    double* loc_dep = all_dep + (size_t)me * cells;
+    PTR_TRY(rc_enqueue(c, cam, n_local, static_cast<const double*>(d_hit_xyz), static_cast<double*>(d_age), age_factor, depth_threshold,
+                       static_cast<int32_t*>(d_item_pixel), loc_el, loc_dep, s, item_base));
+    if (n > 1) {
+        Rccl& r = rccl();
+        if (!r.ok) return fail(c, PTR_ERR_UNSUPPORTED, "%s", r.why);
+        RCCL_TRY(c, r.GroupStart());                                    // in place: each rank's grid already sits at its offset
+        const int rc1 = r.AllGather(loc_el, all_el, cells, RCCL_INT32, c->comm, s);
+        const int rc2 = rc1 == 0 ? r.AllGather(loc_dep, all_dep, cells, RCCL_FLOAT64, c->comm, s) : 0;
+        const int rc3 = r.GroupEnd();
+        if (rc1 != 0 || rc2 != 0 || rc3 != 0)
+            return fail(c, PTR_ERR_HIP, "ncclAllGather failed: %s", r.GetErrorString(rc1 ? rc1 : rc2 ? rc2 : rc3));
+    }
+    return rc_merge_enqueue(c, cam->width, cam->height, n, me, all_el, all_dep, n_local, item_base, d_age, age_factor, depth_threshold,
+                            d_item_pixel, d_pixel_element, d_pixel_depth, s);
 }
 
 int ptr_gather_strips_device(ptr_ctx* c, int width, int height, int strip_height, int n_frames,

@@ -196,6 +196,7 @@ struct TraceArgs {
 struct RcArgs {
     double from[3], view[16], proj[16];      // camera.from, matrixWorldInverse, projectionMatrix (column-major)
     int32_t width, height, n_items;
+    int32_t item_base;                       // a shard of a cache split over several GPUs: index of its first item in the whole cache
     double age_factor, depth_threshold;
     const double* hit_xyz;                   // 3 per item, NaN in x = no hit
     double* age;                             // in/out
@@ -205,6 +206,20 @@ struct RcArgs {
     // scratch owned by the context
     double* item_depth;
     uint32_t *sort_key, *sort_val, *sorted_key, *sorted_val;
+};
+
+// reprojection of a cache whose items are split over several GPUs in cache order: what every rank does after all ranks'
+// local grids (nearest local item per pixel and its depth) have been gathered (ptr_kernels_rc.hip)
+struct RcMergeArgs {
+    int32_t width, height, n_items, item_base;   // this rank's items
+    int32_t n_ranks, rank;
+    double age_factor, depth_threshold;
+    const double* all_depth;                 // n_ranks x grid: every rank's local pixel_depth
+    const int32_t* all_element;              // n_ranks x grid: every rank's local pixel_element (indices in the whole cache)
+    double* age; int32_t* item_pixel;        // this rank's items, as its local pass left them
+    const double* item_depth;                // scratch of the local pass
+    int32_t* pixel_element; double* pixel_depth;     // out: the grid of the whole cache
+    double* before;                          // scratch, grid: nearest depth among the items of the ranks before this one
 };
 
 // render cache depth culling + gap filling + frames (ptr_kernels_rc.hip); all pointers are device memory

@@ -26,6 +26,7 @@ hipError_t launch_render_ext(const RenderArgs& a, int n_frames, bool f64, bool s
 hipError_t launch_rc_shade(const RcShadeArgs& a, hipStream_t s);
 size_t rc_sort_temp_bytes(int n_items, int width, int height);
 hipError_t launch_rc_reproject(const RcArgs& a, void* sort_temp, size_t sort_temp_bytes, hipStream_t s);
+hipError_t launch_rc_merge(const RcMergeArgs& a, hipStream_t s);      // the cache split over several GPUs: after the gather
 
 // render cache frame loop on a resident cache (ptr_kernels_rcloop.hip): threshold + candidate walk; picks, diffusion,
 // allocator, ray directions; results into the cache + ageing; the four frames

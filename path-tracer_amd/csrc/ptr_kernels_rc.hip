@@ -93,8 +93,45 @@ __global__ void __launch_bounds__(256) rc_resolve_kernel(RcArgs a)
             a.age[i] += a.age_factor;                       // Driver.js:468
         }
     }
-    a.pixel_element[p] = element;
+    a.pixel_element[p] = element < 0 ? -1 : element + a.item_base;
     a.pixel_depth[p] = depth;
+}
+
+// ---- the same pass for a cache split over several GPUs in cache order (multi-GPU) ---------
+// Rank r holds items [base_r, base_r + n_r) and runs the pass above on them alone.  What the sequential walk over the
+// WHOLE cache would have left follows from the ranks' local grids (gathered, 12 B per pixel and rank):
+//   * the pixel's element is the local winner of the first rank that reaches the smallest local depth (within a rank
+//     the local winner already is the first item of that depth);
+//   * every item on the pixel except that one is aged once: the local pass aged all local losers, so the only item
+//     left to age is a local winner that loses against another rank;
+//   * an item keeps its pixel pointer when it was nearer than everything before it in cache order: nearer than the
+//     earlier items of its own rank (the local pass decided that) AND than the nearest item of all earlier ranks.
+__global__ void __launch_bounds__(256) rc_merge_pixels_kernel(RcMergeArgs a)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x + 1, y = blockIdx.y + 1;
+    if (x > a.width) return;
+    const size_t cells = (size_t)(a.width + 2) * (a.height + 2), p = (size_t)y * (a.width + 2) + x;
+    double best = a.depth_threshold, before = a.depth_threshold;
+    int element = -1, winner = -1;
+    for (int r = 0; r < a.n_ranks; r++) {
+        if (r == a.rank) before = best;
+        const int e = a.all_element[r * cells + p];
+        const double d = a.all_depth[r * cells + p];
+        if (e >= 0 && d < best) { best = d; element = e; winner = r; }
+    }
+    const int mine = a.all_element[a.rank * cells + p];
+    if (mine >= 0 && winner != a.rank) a.age[mine - a.item_base] += a.age_factor;
+    a.pixel_element[p] = element;
+    a.pixel_depth[p] = best;
+    a.before[p] = before;
+}
+
+__global__ void __launch_bounds__(256) rc_merge_items_kernel(RcMergeArgs a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_items) return;
+    const int p = a.item_pixel[i];
+    if (p >= 0 && !(a.item_depth[i] < a.before[p])) a.item_pixel[i] = -1;
 }
 
 // Keys are pixel indices of the padded grid, or all ones: with 2^bits > cells, all ones stays the largest key
@@ -241,6 +278,13 @@ hipError_t launch_rc_shade(const RcShadeArgs& a, hipStream_t s)
     hipLaunchKernelGGL(rc_cull_kernel, grid, dim3(256), 0, s, a);
     dim3 fill_grid(grid.x, a.height < 128 ? a.height : 128);
     hipLaunchKernelGGL(rc_fill_kernel, fill_grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_rc_merge(const RcMergeArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(rc_merge_pixels_kernel, dim3((a.width + 255) / 256, a.height), dim3(256), 0, s, a);
+    if (a.n_items > 0) hipLaunchKernelGGL(rc_merge_items_kernel, dim3((a.n_items + 255) / 256), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -36,14 +36,17 @@ __device__ __forceinline__ int rc_last_pixel(const RcLoopArgs& a)      // where 
 }
 
 // Driver.js:690-706.  `samples === null` only for the first level; a budget that is never exceeded leaves threshold null.
-__global__ void rc_threshold_kernel(RcLoopArgs a)
+__global__ void __launch_bounds__(256) rc_threshold_kernel(RcLoopArgs a)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    __shared__ double level[256];                               // URGENT + INTERPOLATED + SAMPLED per priority level
+    level[threadIdx.x] = (double)a.hist[256 + threadIdx.x] + (double)a.hist[threadIdx.x] + (double)a.hist[512 + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     double samples = 0;
     bool first = true;
     int threshold = -1;
     for (int i = a.priority_max; i >= 0; i--) {
-        double test = (double)a.hist[256 + i] + (double)a.hist[i] + (double)a.hist[512 + i];    // URGENT + INTERPOLATED + SAMPLED
+        double test = level[i];
         if (first) { samples = test; test = 0; first = false; }
         if (samples + test > a.max_samples) { threshold = i; samples += test; break; }
         samples += test;
@@ -197,6 +200,9 @@ __global__ void __launch_bounds__(256) rc_store_kernel(RcLoopArgs a)
 // age(ageFactor, cache) (:113, :936-942) and getCacheUsage's count
 __global__ void __launch_bounds__(256) rc_age_kernel(RcLoopArgs a)
 {
+    __shared__ int block_used;
+    if (threadIdx.x == 0) block_used = 0;
+    __syncthreads();
     int used = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n_items; i += gridDim.x * blockDim.x) {
         a.item_age[i] += a.age_factor;
@@ -204,7 +210,9 @@ __global__ void __launch_bounds__(256) rc_age_kernel(RcLoopArgs a)
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) used += __shfl_xor(used, off, 64);
-    if ((threadIdx.x & 63) == 0 && used) atomicAdd(&a.words->used, used);
+    if ((threadIdx.x & 63) == 0 && used) atomicAdd(&block_used, used);
+    __syncthreads();
+    if (threadIdx.x == 0 && block_used) atomicAdd(&a.words->used, block_used);      // one address: ~88 atomics per microsecond
 }
 
 // getColorFrame / getReprojectionFrame / getPriorityFrame / getSamplingFrame (:960-1046) from the live state, rows bottom-up
@@ -240,7 +248,7 @@ size_t rc_loop_temp_bytes(int width, int height)
 
 hipError_t launch_rc_candidates(const RcLoopArgs& a, void* temp, size_t temp_bytes, hipStream_t s)
 {
-    hipLaunchKernelGGL(rc_threshold_kernel, dim3(1), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(rc_threshold_kernel, dim3(1), dim3(256), 0, s, a);
     WalkIterator walk(hipcub::CountingInputIterator<int>(0), WalkPixel{a.width});
     return hipcub::DeviceSelect::If(temp, temp_bytes, walk, a.cand, &a.words->candidates, a.width * a.height,
                                     AtThreshold{a.pixel_priority, a.words}, s);
@@ -269,7 +277,7 @@ hipError_t launch_rc_store(const RcLoopArgs& a, hipStream_t s)
 {
     if (a.n_picks > 0) hipLaunchKernelGGL(rc_store_kernel, blocks_for(a.n_picks), dim3(256), 0, s, a);
     const int blocks = (a.n_items + 255) / 256;
-    hipLaunchKernelGGL(rc_age_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(rc_age_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

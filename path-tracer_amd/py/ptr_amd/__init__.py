@@ -33,6 +33,7 @@ SYMBOLS = [
     "ptr_gather_strips_device", "ptr_gather_strips_all", "ptr_place_strips_device", "ptr_render_multi",
     "ptr_rc_cache_create", "ptr_rc_cache_destroy", "ptr_rc_cache_shape", "ptr_rc_cache_upload", "ptr_rc_cache_download",
     "ptr_rc_next_frame", "ptr_rc_get_frames",
+    "ptr_rc_reproject_shard_device", "ptr_rc_merge_shards_device", "ptr_rc_reproject_multi_device",
 ]
 
 
@@ -175,6 +176,10 @@ def lib():
         L.ptr_gather_strips_all.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.c_uint64, vp]
         L.ptr_place_strips_device.argtypes = [vp, C.POINTER(Strips), C.c_int, C.c_int, C.c_int, vp, C.c_uint64, vp, vp]
         L.ptr_render_multi.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(Params), C.POINTER(C.c_uint32)]
+        L.ptr_rc_reproject_shard_device.argtypes = [vp, C.POINTER(RcCamera), C.c_int, C.c_int, vp, vp, C.c_double, C.c_double, vp, vp, vp, vp]
+        L.ptr_rc_merge_shards_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_double, C.c_double,
+                                                 vp, vp, vp, vp]
+        L.ptr_rc_reproject_multi_device.argtypes = [vp, C.POINTER(RcCamera), C.c_int, C.c_int, vp, vp, C.c_double, C.c_double, vp, vp, vp, vp]
         L.ptr_rc_cache_create.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         L.ptr_rc_cache_destroy.argtypes = [vp]
         L.ptr_rc_cache_destroy.restype = None
@@ -462,6 +467,25 @@ class Renderer:
         ptrs = [out[k].ctypes.data_as(C.POINTER(C.c_uint32)) if k in out else None for k in names]
         self._check(self._L.ptr_rc_get_frames(self._h, *ptrs))
         return out
+
+    # ---- reprojection of a cache split over several GPUs (device pointers as integers) ----
+    def rc_reproject_shard_device(self, cam, n_local, item_base, d_hit, d_age, d_item_pixel, d_local_el, d_local_dep,
+                                  age_factor=1.0, depth_threshold=1e6, stream=None):
+        self._check(self._L.ptr_rc_reproject_shard_device(self._h, C.byref(cam), n_local, item_base, C.c_void_p(d_hit), C.c_void_p(d_age),
+                                                          age_factor, depth_threshold, C.c_void_p(d_item_pixel), C.c_void_p(d_local_el),
+                                                          C.c_void_p(d_local_dep), C.c_void_p(stream or 0)))
+
+    def rc_merge_shards_device(self, width, height, n_ranks, rank, d_all_el, d_all_dep, n_local, item_base, d_age, d_item_pixel, d_pel,
+                               d_pdep, age_factor=1.0, depth_threshold=1e6, stream=None):
+        self._check(self._L.ptr_rc_merge_shards_device(self._h, width, height, n_ranks, rank, C.c_void_p(d_all_el), C.c_void_p(d_all_dep),
+                                                       n_local, item_base, C.c_void_p(d_age), age_factor, depth_threshold,
+                                                       C.c_void_p(d_item_pixel), C.c_void_p(d_pel), C.c_void_p(d_pdep), C.c_void_p(stream or 0)))
+
+    def rc_reproject_multi_device(self, cam, n_local, item_base, d_hit, d_age, d_item_pixel, d_pel, d_pdep, age_factor=1.0,
+                                  depth_threshold=1e6, stream=None):
+        self._check(self._L.ptr_rc_reproject_multi_device(self._h, C.byref(cam), n_local, item_base, C.c_void_p(d_hit), C.c_void_p(d_age),
+                                                          age_factor, depth_threshold, C.c_void_p(d_item_pixel), C.c_void_p(d_pel),
+                                                          C.c_void_p(d_pdep), C.c_void_p(stream or 0)))
 
     def trace_batch(self, dirs, want_hit=False):
         dirs = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)

@@ -56,3 +56,44 @@ def test_strip_partition_and_gather_gloo(world, strip, h):
     port = 29650 + world * 7 + strip
     mp.spawn(_worker, args=(world, port, strip, 64, h, ret), nprocs=world, join=True)
     assert ret.get("ok") is True
+
+
+def _reproject_worker(rank, world, port, ret):
+    """configs[4], the render cache's reprojection with the cache split over ranks: every rank runs the pass on its
+    items (the CPU oracle here, ptr_rc_reproject_shard_device on a GPU), the local grids are all-gathered (gloo here,
+    ncclAllGather in ptr_rc_reproject_multi_device), and the merge rule of ptr_rc_merge_shards_device (its numpy model)
+    gives every rank its part of the reference's sequential result."""
+    sys.path[:0] = [os.path.join(ROOT, "oracle"), os.path.join(ROOT, "path-tracer_amd", "py"), os.path.join(ROOT, "tests"), ROOT]
+    import test_rc_reproject as t
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = True
+    for name, c in t.load_cases(os.path.join(ROOT, "tests", "golden")):
+        lo, hi = t.shard_bounds(c["items"], world)[rank]
+        age, ip, el, dep, item_depth = t.local_pass_oracle(c, lo, hi)
+        inner = np.zeros((c["height"] + 2, c["width"] + 2), dtype=bool); inner[1:-1, 1:-1] = True
+        dep = np.where(inner.ravel(), dep, float(c["depth_threshold"]))          # (the pass leaves the border alone)
+        el_t, dep_t = torch.from_numpy(el.copy()), torch.from_numpy(dep)
+        all_el = [torch.zeros_like(el_t) for _ in range(world)]
+        all_dep = [torch.zeros_like(dep_t) for _ in range(world)]
+        dist.all_gather(all_el, el_t)
+        dist.all_gather(all_dep, dep_t)
+        age, ip, pel, pdep = t.merge_shards_model(rank, lo, (age, ip), torch.stack(all_el).numpy(), torch.stack(all_dep).numpy(),
+                                                  item_depth, c["age_factor"], c["depth_threshold"])
+        # every rank holds the whole grid; its items are its slice of the reference's arrays
+        ok = ok and np.array_equal(age, c["age_out"][lo:hi]) and np.array_equal(ip, c["item_pixel"][lo:hi])
+        ok = ok and np.array_equal(pel[inner.ravel()], c["pixel_element"][inner.ravel()])
+        ok = ok and np.array_equal(pdep[inner.ravel()], c["pixel_depth"][inner.ravel()])
+    flags = [None] * world
+    dist.all_gather_object(flags, bool(ok))
+    if rank == 0:
+        ret["ok"] = all(flags)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_reprojection_gloo(world):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_reproject_worker, args=(world, 29720 + world, ret), nprocs=world, join=True)
+    assert ret.get("ok") is True
