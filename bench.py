@@ -125,6 +125,125 @@ def cpu_baseline_js(seconds=8.0):
                       f"worker_threads, node {r['node']}"}
 
 
+def rc_reprojection_line(ptr_amd, torch, dist, rdr, world, rank, backend, library_comm, stream, steps):
+    """BASELINE.json configs[4], second half: the render cache's point reprojection (rendercache-js Driver.reprojectFrame) of a
+    1080p cache (4 items per pixel, synthetic hit points), the cache's items split over the ranks in cache order (strong scaling:
+    the cache is the same at every N).  Every rank: local pass, all-gather of the local grids (12 B per pixel and rank), merge.
+    Checked before it is timed: rank 0 also runs the whole cache alone and compares the grid and its own items."""
+    W, H, FACTOR = 1920, 1080, 4
+    n, cells = W * H * FACTOR, (W + 2) * (H + 2)
+    rng = np.random.default_rng(7)
+    hits = np.stack([rng.uniform(-30, 30, n), rng.uniform(-6, 14, n), rng.uniform(-60, -8, n)], axis=1)
+    hits[rng.random(n) < 0.2, 0] = np.nan
+    age0 = rng.integers(0, 30, n).astype(np.float64)
+    rec = np.fromfile(os.path.join(ROOT, "tests", "golden", "rc", "reproject_move_96x64.f64"), count=35)
+    proj = rec[19:35].copy(); proj[0] = proj[5] / (W / H)
+    cam = rdr.rc_camera(rec[0:3], rec[3:19], proj, W, H)
+    lo, hi = n * rank // world, n * (rank + 1) // world
+    m = hi - lo
+    d_hit = torch.from_numpy(hits[lo:hi]).cuda()
+    d_age0 = torch.from_numpy(age0[lo:hi]).cuda()
+    d_age = d_age0.clone()
+    d_ip = torch.empty(m, dtype=torch.int32, device="cuda")
+    d_pel = torch.full((cells,), -1, dtype=torch.int32, device="cuda")
+    d_pdep = torch.full((cells,), 1e6, dtype=torch.float64, device="cuda")
+    all_el = torch.full((world, cells), -1, dtype=torch.int32, device="cuda")
+    all_dep = torch.full((world, cells), 1e6, dtype=torch.float64, device="cuda")
+    mode = ["one GPU" if world == 1 else ("library (ncclAllGather)" if library_comm else "torch.distributed all_gather")]
+    dev = "cuda" if backend == "nccl" else "cpu"
+
+    def one_pass():
+        if world == 1:
+            rdr.rc_reproject_device(cam, n, d_hit.data_ptr(), d_age.data_ptr(), d_ip.data_ptr(), d_pel.data_ptr(), d_pdep.data_ptr(), stream=stream)
+        elif mode[0].startswith("library"):
+            rdr.rc_reproject_multi_device(cam, m, lo, d_hit.data_ptr(), d_age.data_ptr(), d_ip.data_ptr(), d_pel.data_ptr(), d_pdep.data_ptr(),
+                                          stream=stream)
+        else:
+            rdr.rc_reproject_shard_device(cam, m, lo, d_hit.data_ptr(), d_age.data_ptr(), d_ip.data_ptr(), all_el[rank].data_ptr(),
+                                          all_dep[rank].data_ptr(), stream=stream)
+            if backend == "nccl":
+                dist.all_gather_into_tensor(all_el, all_el[rank].clone())
+                dist.all_gather_into_tensor(all_dep, all_dep[rank].clone())
+            else:                                      # rehearsal: through the host
+                torch.cuda.synchronize()
+                for t in (all_el, all_dep):
+                    parts = [torch.empty(cells, dtype=t.dtype) for _ in range(world)]
+                    dist.all_gather(parts, t[rank].cpu())
+                    t.copy_(torch.stack(parts))
+            rdr.rc_merge_shards_device(W, H, world, rank, all_el.data_ptr(), all_dep.data_ptr(), m, lo, d_age.data_ptr(), d_ip.data_ptr(),
+                                       d_pel.data_ptr(), d_pdep.data_ptr(), stream=stream)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def checked_pass():
+        """-> (raised, good) agreed by all ranks"""
+        d_age.copy_(d_age0)
+        err = 0
+        try:
+            one_pass()
+            torch.cuda.synchronize()
+        except ptr_amd.PtrError as e:
+            print(f"rank {rank}: reprojection: {e}", file=sys.stderr)
+            err = 1
+        if world > 1:
+            flag = torch.tensor([err], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            err = int(flag.item())
+        good = 1
+        if rank == 0 and not err:
+            r1 = ptr_amd.Renderer(torch.cuda.current_device())
+            w_hit, w_age = torch.from_numpy(hits).cuda(), torch.from_numpy(age0).cuda()
+            w_ip = torch.empty(n, dtype=torch.int32, device="cuda")
+            w_pel = torch.full((cells,), -1, dtype=torch.int32, device="cuda")
+            w_pdep = torch.full((cells,), 1e6, dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            r1.rc_reproject_device(cam, n, w_hit.data_ptr(), w_age.data_ptr(), w_ip.data_ptr(), w_pel.data_ptr(), w_pdep.data_ptr())
+            r1.sync()
+            inner = torch.zeros((H + 2, W + 2), dtype=torch.bool, device="cuda"); inner[1:-1, 1:-1] = True
+            inner = inner.reshape(-1)
+            good = int(torch.equal(w_pel[inner], d_pel[inner]) and torch.equal(w_pdep[inner], d_pdep[inner]) and
+                       torch.equal(w_age[lo:hi], d_age) and torch.equal(w_ip[lo:hi], d_ip))
+            r1.close()
+        if world > 1:
+            flag = torch.tensor([good], dtype=torch.int32, device=dev)
+            dist.broadcast(flag, src=0)
+            good = int(flag.item())
+        return err, good
+
+    err, good = checked_pass()
+    if (err or not good) and mode[0].startswith("library"):
+        mode[0] = "torch.distributed all_gather (the library's exchange " + ("raised an error)" if err else "failed its check)")
+        err, good = checked_pass()
+    if err or not good:
+        return {"error": "the sharded pass does not reproduce the single-GPU pass; not timed"}
+    for _ in range(2):
+        one_pass()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_pass()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / steps * 1e3
+    alg = n * (24 + 8 + 8 + 4) + W * H * 12          # per item: hit, age read + written, pixel pointer; per pixel: element + depth
+    return {"workload": f"BASELINE.json configs[4]: render-cache point reprojection, {W}x{H} cache of {n} items"
+                        + (f" split over {world} GPUs in cache order" if world > 1 else ""),
+            "value": round(n / ms / 1e3, 1), "unit": "Mitems/s", "ms_per_pass": round(ms, 4), "n_gpus": world, "scaling": "strong",
+            "dtype": "f64", "exchange": mode[0], "exchanged_bytes_into_each_rank": int(12 * cells * (world - 1)),
+            "checked": "grid and rank 0's items equal the single-GPU pass over the whole cache",
+            "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                         "frac": round(alg / ms / 1e6 / PEAK_HBM_GBPS, 4), "algorithmic_bytes": alg,
+                         "note": "algorithmic bytes of the whole cache / the wall time of a pass (all ranks, exchange included)"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,6 +251,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)      # (the chip needs several launches to reach its clocks)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rc", action="store_true", help="skip the render-cache reprojection line (BASELINE configs[4])")
     ap.add_argument("--check", action="store_true", help="after timing, compare rank 0's gathered frame 0 with a single-GPU render")
     args = ap.parse_args()
 
@@ -451,6 +571,12 @@ def main():
                                                "ray count scaled from a 960x540 counting run"}
         r3.close()
 
+    # ---- BASELINE.json configs[4], second half: the render cache's reprojection pass, the cache split over the ranks
+    rc_line = None
+    if not args.no_rc:
+        rc_line = rc_reprojection_line(ptr_amd, torch, dist, rdr, world, rank, backend if world > 1 else "none",
+                                       bool(gather_mode == "library"), stream, max(5, min(args.steps, 20)))
+
     if rank == 0:
         share = local_rows / HEIGHT                      # fraction of every frame this rank renders
         total_rays = rays_per_frame * frames_total       # all ranks together, per step
@@ -503,6 +629,8 @@ def main():
                 out["config3_4k_256spp"] = config3
         if depth5 is not None:
             out["extension_depth5"] = depth5
+        if rc_line is not None:
+            out["config5_rc_reprojection"] = rc_line
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(soa, bg)
             out["cpu_baseline_js"] = cpu_baseline_js()
