@@ -479,6 +479,12 @@ int  ptr_rc_cache_download(ptr_ctx *ctx, int32_t *item_pixel, double *item_hit_x
  * exist (every priority outside 0..255): that state is refused with PTR_ERR_INVALID, the cache is then as the
  * shading pass left it.                                                                                         */
 int  ptr_rc_next_frame(ptr_ctx *ctx, const ptr_rc_view *view, const ptr_rc_loop_params *params, ptr_rc_frame_stats *out);
+/* The candidate numbers Driver.directSamples requests (:795-822: `index += requestFactor`, Math.round, no number twice,
+ * none >= n_candidates), as ptr_rc_next_frame computes them: in closed form, piece by piece of the float64 running sum,
+ * instead of adding it up.  Host only (no GPU is touched).  Returns how many were written to out, PTR_ERR_INVALID for a
+ * request factor with which the reference's loop would not end or a capacity that is too small, PTR_ERR_UNSUPPORTED when
+ * the sum has more pieces than the table holds (ptr_rc_next_frame then adds it up step by step).                  */
+int  ptr_rc_pick_sequence(double request_factor, int n_candidates, int32_t *out, int capacity);
 /* getColorFrame / getReprojectionFrame / getPriorityFrame / getSamplingFrame (:960-1046) from the live state: width *
  * height RGBA8 words each, rows bottom-up, HOST pointers, any may be NULL.                                       */
 int  ptr_rc_get_frames(ptr_ctx *ctx, uint32_t *color_frame, uint32_t *reprojection_frame, uint32_t *priority_frame,

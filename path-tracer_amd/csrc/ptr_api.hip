@@ -1216,6 +1216,55 @@ int rc_cache_ready(ptr_ctx* c, bool need_state)
     return PTR_OK;
 }
 
+// Driver.directSamples' pick loop (Driver.js:795-822) as pieces of RcPickSegments.  n_cand >= 1, rf > 0.  Returns false when
+// the table would overflow (the caller then adds the sum up step by step).  *n_picks = how many candidates are requested.
+bool rc_pick_segments(double rf, int n_cand, RcPickSegments* g, long long* n_picks)
+{
+    g->n = 0; g->pad = 0;
+    auto push = [&](long long k, long long S, long long D, int e) {
+        if (g->n >= 96 || k > 0x7fffffffll) return false;
+        g->k0[g->n] = (int32_t)k; g->S0[g->n] = S; g->D[g->n] = D; g->e[g->n] = e;
+        g->n++;
+        return true;
+    };
+    if (rf <= 1) {                  // the rounded sum moves by 0 or 1 per step: every candidate is requested, once
+        *n_picks = n_cand;
+        return push(0, 0, 1, 0);
+    }
+    const double C = (double)n_cand;
+    if (!push(0, 0, 0, 0)) return false;                // step 0: the sum is 0
+    long long k = 1;
+    double s = rf, last = 0;                            // 0 + rf is exact
+    while (s < C) {
+        int ex;
+        (void)std::frexp(s, &ex);                       // 2^(ex-1) <= s < 2^ex: one unit in the last place is 2^(ex-53)
+        const int e = ex - 53;
+        const double top = std::ldexp(1.0, ex);
+        const long long S = (long long)std::ldexp(s, -e);
+        const double s1 = s + rf, s2 = s1 + rf;
+        long long D = 0, cnt = 1;
+        // a constant step while the sum stays below `top` (a tie of the rounding may take one step to settle: checked on two)
+        if (s1 < top && (s2 >= top || std::ldexp(s2 - s1, -e) == std::ldexp(s1 - s, -e))) {
+            D = (long long)std::ldexp(s1 - s, -e);
+            const long long L = (long long)std::ceil(std::ldexp(top < C ? top : C, -e));
+            cnt = (L - S + D - 1) / D;
+        }
+        if (!push(k, S, D, e)) return false;
+        k += cnt;
+        last = std::ldexp((double)(S + (cnt - 1) * D), e);
+        s = last + rf;
+    }
+    *n_picks = js_round(last) < C ? k : k - 1;          // `if (i < candidates.length)` can only fail for the last step
+    return true;
+}
+
+int32_t rc_pick_at(const RcPickSegments& g, long long k)       // what rc_pick_index_kernel computes for step k
+{
+    int seg = 0;
+    while (seg + 1 < g.n && k >= g.k0[seg + 1]) seg++;
+    return (int32_t)js_round(std::ldexp((double)(g.S0[seg] + (k - g.k0[seg]) * g.D[seg]), g.e[seg]));
+}
+
 RcLoopArgs rc_loop_args(const RcCache& r)
 {
     RcLoopArgs a;
@@ -1229,7 +1278,7 @@ RcLoopArgs rc_loop_args(const RcCache& r)
     unsigned char* w = static_cast<unsigned char*>(r.words.ptr);
     a.hist = reinterpret_cast<const uint32_t*>(w + RC_WORDS_HIST);
     a.words = reinterpret_cast<RcLoopWords*>(w + RC_WORDS_LOOP);
-    a.cand = static_cast<int32_t*>(r.cand.ptr); a.pick_index = static_cast<const int32_t*>(r.picks.ptr);
+    a.cand = static_cast<int32_t*>(r.cand.ptr); a.pick_index = static_cast<int32_t*>(r.picks.ptr);
     a.pick_item = static_cast<int32_t*>(r.pick_item.ptr); a.need = static_cast<int32_t*>(r.need.ptr); a.rank = static_cast<int32_t*>(r.rank.ptr);
     a.dirs = static_cast<double*>(r.dirs.ptr); a.tr_rgb = static_cast<const double*>(r.tr_rgb.ptr); a.tr_hit = static_cast<const double*>(r.tr_hit.ptr);
     return a;
@@ -1410,22 +1459,31 @@ int ptr_rc_next_frame(ptr_ctx* c, const ptr_rc_view* view, const ptr_rc_loop_par
     const double rf = lw.samples / par->max_samples_per_frame;          // :708
     const double n_cand = (double)lw.candidates;
     int n_picks = 0;
+    RcPickSegments segs;
+    bool closed_form = false;
     if (lw.candidates > 0) {
         if (!(rf > 0) || n_cand / rf > 4.0e9)
             return fail(c, PTR_ERR_INVALID, "request factor %g with %d candidates: the reference's pick loop (Driver.js:795-822) would "
                                             "not end", rf, lw.candidates);
-        double index = 0, last_i = -1;                                  // :795-822; lastI === null is the -1 here
-        while (index < n_cand) {
-            const double i = js_round(index);
-            if (i != last_i && i < n_cand) r.host_picks[n_picks++] = (int32_t)i;
-            last_i = i;
-            index += rf;
+        long long np = 0;
+        closed_form = rc_pick_segments(rf, lw.candidates, &segs, &np);
+        if (closed_form) {
+            n_picks = (int)np;
+        } else {                                                        // (more pieces than the table holds: add the sum up here)
+            double index = 0, last_i = -1;                              // :795-822; lastI === null is the -1 here
+            while (index < n_cand) {
+                const double i = js_round(index);
+                if (i != last_i && i < n_cand) r.host_picks[n_picks++] = (int32_t)i;
+                last_i = i;
+                index += rf;
+            }
+            segs.n = 0;
         }
     }
     a.n_picks = n_picks;
     if (n_picks > 0) {
-        HIP_TRY(c, hipMemcpyAsync(r.picks.ptr, r.host_picks, (size_t)n_picks * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, launch_rc_requests(a, r.temp.ptr, r.temp.bytes, s));
+        if (!closed_form) HIP_TRY(c, hipMemcpyAsync(r.picks.ptr, r.host_picks, (size_t)n_picks * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, launch_rc_requests(a, segs, r.temp.ptr, r.temp.bytes, s));
         TraceArgs t;                                                    // requestSamples: Sample.doRaytracing for every request
         std::memset(&t, 0, sizeof t);
         t.scene = static_cast<const unsigned char*>(c->scenes.ptr);
@@ -1447,6 +1505,19 @@ int ptr_rc_next_frame(ptr_ctx* c, const ptr_rc_view* view, const ptr_rc_loop_par
     out->total_priority_increment = (double)totals[2];
     out->cache_usage = (double)lw.used / (double)r.n_items;
     return PTR_OK;
+}
+
+int ptr_rc_pick_sequence(double request_factor, int n_candidates, int32_t* out, int capacity)
+{
+    if (n_candidates < 0 || capacity < 0 || (capacity > 0 && !out)) return PTR_ERR_INVALID;
+    if (n_candidates == 0) return 0;
+    if (!(request_factor > 0) || (double)n_candidates / request_factor > 4.0e9) return PTR_ERR_INVALID;
+    RcPickSegments g;
+    long long n = 0;
+    if (!rc_pick_segments(request_factor, n_candidates, &g, &n)) return PTR_ERR_UNSUPPORTED;
+    if (n > capacity) return PTR_ERR_INVALID;
+    for (long long k = 0; k < n; k++) out[k] = rc_pick_at(g, k);
+    return (int)n;
 }
 
 int ptr_rc_get_frames(ptr_ctx* c, uint32_t* color_frame, uint32_t* reprojection_frame, uint32_t* priority_frame, uint32_t* sampling_frame)

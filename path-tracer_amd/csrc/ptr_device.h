@@ -256,6 +256,17 @@ struct RcLoopWords {
 constexpr size_t RC_WORDS_HIST = 0, RC_WORDS_TOTALS = 3 * 256 * sizeof(uint32_t),
                  RC_WORDS_LOOP = RC_WORDS_TOTALS + 3 * sizeof(long long), RC_WORDS_BYTES = RC_WORDS_LOOP + sizeof(RcLoopWords);
 
+// The picks of Driver.directSamples (:795-822) in closed form.  `index += requestFactor` in float64 moves by a constant
+// number of units in the last place while the sum stays within one power of two, so the running sum is piecewise
+// S0 + j * D (integers below 2^53) times 2^e: the host finds the pieces (one or two per power of two), a lane evaluates
+// its own step.  Step k of piece `seg` is s = (S0 + (k - k0) * D) * 2^e, the pick is Math.round(s).
+struct RcPickSegments {
+    int32_t n, pad;
+    int32_t k0[96];                  // first step of the piece
+    int32_t e[96];
+    long long S0[96], D[96];
+};
+
 struct RcLoopArgs {
     int32_t width, height, n_items, n_picks;
     int32_t pages, priority_max, rank_lo, rank_hi;
@@ -267,7 +278,7 @@ struct RcLoopArgs {
     const uint32_t* hist; RcLoopWords* words;
     // this frame's requests
     int32_t* cand;                   // candidate pixels in walk order
-    const int32_t* pick_index;       // which candidates are requested
+    int32_t* pick_index;             // which candidates are requested
     int32_t *pick_item, *need, *rank;
     double* dirs; const double* tr_rgb; const double* tr_hit;
     uint32_t* frames[4];             // colour, reprojection, priority, sampling (nullable), width * height each

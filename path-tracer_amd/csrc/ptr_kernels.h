@@ -32,7 +32,7 @@ hipError_t launch_rc_merge(const RcMergeArgs& a, hipStream_t s);      // the cac
 // allocator, ray directions; results into the cache + ageing; the four frames
 size_t rc_loop_temp_bytes(int width, int height);
 hipError_t launch_rc_candidates(const RcLoopArgs& a, void* temp, size_t temp_bytes, hipStream_t s);
-hipError_t launch_rc_requests(const RcLoopArgs& a, void* temp, size_t temp_bytes, hipStream_t s);
+hipError_t launch_rc_requests(const RcLoopArgs& a, const RcPickSegments& picks, void* temp, size_t temp_bytes, hipStream_t s);
 hipError_t launch_rc_store(const RcLoopArgs& a, hipStream_t s);
 hipError_t launch_rc_frames(const RcLoopArgs& a, hipStream_t s);
 

@@ -10,8 +10,8 @@
 // The reference does all of this sequentially; the order only matters in three places, and each has a parallel form
 // that gives the same state:
 //   * the candidate list is a stable compaction of the pixels in walk order (hipCUB select over a walk-order iterator);
-//   * the picks are `Math.round` of a running float64 sum: the host adds it up (130 k additions per 1080p frame) and
-//     sends the candidate numbers down;
+//   * the picks are `Math.round` of a running float64 sum, which is piecewise linear in integers (RcPickSegments): the
+//     host finds the few pieces, every lane evaluates its own step;
 //   * the diffused amount depends on the priority of ONE pixel, the last of the walk, which only two picks can change
 //     (its upper and its inner neighbour): three amounts, computed by one lane, cover every pick;
 //   * the allocator hands the k-th request that needs an item the k-th page after the pointer: an exclusive sum of the
@@ -77,6 +77,17 @@ struct AtThreshold {
     const RcLoopWords* words;
     __device__ bool operator()(int p) const { return priority[p] >= words->thr_value; }
 };
+
+// which candidate step k requests: Math.round of the running sum (see RcPickSegments)
+__global__ void __launch_bounds__(256) rc_pick_index_kernel(int32_t* pick_index, int n_picks, RcPickSegments g)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_picks) return;
+    int seg = 0;
+    while (seg + 1 < g.n && k >= g.k0[seg + 1]) seg++;
+    const long long S = g.S0[seg] + (long long)(k - g.k0[seg]) * g.D[seg];
+    pick_index[k] = (int32_t)js_round(__builtin_scalbn((double)S, g.e[seg]));
+}
 
 __global__ void __launch_bounds__(256) rc_pick_kernel(RcLoopArgs a)
 {
@@ -254,10 +265,11 @@ hipError_t launch_rc_candidates(const RcLoopArgs& a, void* temp, size_t temp_byt
                                     AtThreshold{a.pixel_priority, a.words}, s);
 }
 
-hipError_t launch_rc_requests(const RcLoopArgs& a, void* temp, size_t temp_bytes, hipStream_t s)
+hipError_t launch_rc_requests(const RcLoopArgs& a, const RcPickSegments& picks, void* temp, size_t temp_bytes, hipStream_t s)
 {
     if (a.n_picks <= 0) return hipSuccess;
     const dim3 grid = blocks_for(a.n_picks);
+    if (picks.n > 0) hipLaunchKernelGGL(rc_pick_index_kernel, grid, dim3(256), 0, s, a.pick_index, a.n_picks, picks);   // else: the host sent them
     hipLaunchKernelGGL(rc_pick_kernel, grid, dim3(256), 0, s, a);
     hipError_t e = hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, a.need, a.rank, a.n_picks, s);
     if (e != hipSuccess) return e;

@@ -32,7 +32,7 @@ SYMBOLS = [
     "ptr_comm_unique_id", "ptr_comm_init_rank", "ptr_comm_init_all", "ptr_comm_destroy",
     "ptr_gather_strips_device", "ptr_gather_strips_all", "ptr_place_strips_device", "ptr_render_multi",
     "ptr_rc_cache_create", "ptr_rc_cache_destroy", "ptr_rc_cache_shape", "ptr_rc_cache_upload", "ptr_rc_cache_download",
-    "ptr_rc_next_frame", "ptr_rc_get_frames",
+    "ptr_rc_next_frame", "ptr_rc_get_frames", "ptr_rc_pick_sequence",
     "ptr_rc_reproject_shard_device", "ptr_rc_merge_shards_device", "ptr_rc_reproject_multi_device",
 ]
 
@@ -188,6 +188,7 @@ def lib():
         L.ptr_rc_cache_download.argtypes = [vp] * 10 + [C.POINTER(C.c_int64)]
         L.ptr_rc_next_frame.argtypes = [vp, C.POINTER(RcView), C.POINTER(RcLoopParams), C.POINTER(RcFrameStats)]
         L.ptr_rc_get_frames.argtypes = [vp, up, up, up, up]
+        L.ptr_rc_pick_sequence.argtypes = [C.c_double, C.c_int, ip, C.c_int]
         L.ptr_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.ptr_get_kernel_ms.argtypes = [vp, fp, fp]
         _lib = L
@@ -212,6 +213,15 @@ def scene_to_soa(elements):
 
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def rc_pick_sequence(request_factor, n_candidates):
+    """the candidate numbers Driver.directSamples requests, by the library's closed form (host only)"""
+    out = np.empty(max(n_candidates, 1), dtype=np.int32)
+    n = lib().ptr_rc_pick_sequence(float(request_factor), int(n_candidates), out.ctypes.data_as(C.POINTER(C.c_int32)), out.size)
+    if n < 0:
+        raise PtrError(n, "ptr_rc_pick_sequence refused the arguments")
+    return out[:n].copy()
 
 
 def render_multi(renderers, width, height, flags=0, max_depth=0, spp=1, seed=0):

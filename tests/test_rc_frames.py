@@ -194,3 +194,38 @@ def test_gpu_resident_frames_argument_errors(golden_dir):
         r.rc_cache_destroy()
     finally:
         r.close()
+
+
+def pick_loop(rf, n_cand):
+    """Driver.directSamples' pick loop (rendercache-js/src/Driver.js:795-822), statement for statement"""
+    out, index, last = [], 0.0, None
+    while index < n_cand:
+        i = int(np.floor(index + 0.5))                          # Math.round of a non-negative number
+        if last is None or last != i:
+            if i < n_cand:
+                out.append(i)
+        last = i
+        index += rf
+    return np.array(out, dtype=np.int32)
+
+
+def test_pick_sequence_closed_form_equals_the_running_sum():
+    """the library finds the picks piece by piece of the float64 running sum (host code, no GPU): same numbers as adding
+    it up, for request factors with exact ties (dyadic, halves), just above 1, below 1, larger than the candidate count"""
+    import ptr_amd
+    rng = np.random.default_rng(5)
+    cases = [(1.0, 1), (1.0, 1000), (0.999999, 777), (0.25, 9), (1.5, 2), (2.5, 100001), (3.0, 3), (1e9, 12), (7.123456789, 1),
+             (1.0000000000000002, 5000), (16.000000000000004, 250000), (1.1 + 2.2, 99999), (255.5, 2073600), (4.000000001, 2073600)]
+    for t in range(500):
+        c = int(rng.integers(1, 200000)) if t % 3 else int(rng.integers(1, 40))
+        kind = t % 5
+        rf = (float(rng.uniform(1, 40)), float(rng.integers(1, 1 << 20)) / float(1 << int(rng.integers(0, 20))),
+              float(rng.uniform(0.05, 1.0)), 1.0 + float(rng.uniform(0, 1e-3)), float(int(rng.integers(2, 60))) + 0.5)[kind]
+        if c / rf > 5e4:
+            rf = c / 5e4 + 1
+        cases.append((rf, c))
+    for rf, c in cases:
+        assert np.array_equal(ptr_amd.rc_pick_sequence(rf, c), pick_loop(rf, c)), (rf, c)
+    assert ptr_amd.rc_pick_sequence(3.0, 0).size == 0
+    with pytest.raises(ptr_amd.PtrError):
+        ptr_amd.rc_pick_sequence(0.0, 10)                       # the reference's loop would not end
