@@ -122,7 +122,11 @@ def cpu_baseline_js(seconds=8.0):
     return {"value": round(r["mrays_per_s"], 2), "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": f"{r['frames']} frames of the example scene at {WIDTH}x{HEIGHT} in {r['seconds']:.1f} s, "
                       f"oracle/js/cpu_port.mjs (JavaScript port in the reference's object style) on {threads} "
-                      f"worker_threads, node {r['node']}"}
+                      f"worker_threads, node {r['node']}",
+            "unmodified_reference_in_build_container": {
+                "value": 35.6, "unit": "Mrays/s", "cores": 8, "one_thread": 5.29,
+                "note": "not measured in this run: the UNMODIFIED reference under Node 12 worker_threads in the build container "
+                        "(BASELINE.md); it cannot travel to the GPU box, which is why the figures measured here are ports"}}
 
 
 def rc_reprojection_line(ptr_amd, torch, dist, rdr, world, rank, backend, library_comm, stream, steps):
