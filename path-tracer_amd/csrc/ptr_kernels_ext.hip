@@ -259,11 +259,12 @@ __device__ __forceinline__ bool any_lane_x(bool c) { return ballot(c) != 0ull; }
 // The stack of rays that wait (second children only: the reflection stays in registers).  Its entries have strictly
 // increasing depths from bottom to top, so max_depth entries per lane are enough.  The lowest PTR_EXT_LDS_ENTRIES of them
 // live in LDS, [entry][word][lane] (a lane's words are 256 bytes apart: every access is conflict-free), 2 560 bytes per entry
-// and wave: nothing of them ever reaches HBM.  A full-depth LDS image would leave three waves per SIMD at depth 5 (measured
-// 42 % slower), so the rare deeper entries (a chain of internal reflections inside a transparent sphere) go to a per-lane
-// array in scratch memory.
+// and wave: nothing of them ever reaches HBM.  Three entries (7.5 KB per wave) are what five waves per SIMD, the kernel's
+// register-bound occupancy, leave room for: a fourth costs a wave per SIMD (measured 14 % slower), a full-depth image two
+// (42 % slower).  The deeper entries (a chain of internal reflections inside a transparent sphere pushes one refracted ray
+// per bounce) go to a per-lane array in scratch memory: 23 B per pixel of the example frame at depth 5, none at depth <= 3.
 #ifndef PTR_EXT_LDS_ENTRIES
-#define PTR_EXT_LDS_ENTRIES 2
+#define PTR_EXT_LDS_ENTRIES 3
 #endif
 struct RayStack {
     float* base;       // this lane's first word in LDS

@@ -18,6 +18,10 @@ names = {1: "primary band", 2: "origin on surface", 4: "ordering", 8: "far clip"
 print(f"{name} {w}x{h}: flagged {np.count_nonzero(why)} of {w*h} ({100*np.count_nonzero(why)/(w*h):.3f}%)")
 for b, nm in names.items():
     print(f"  {nm:18s} {int(((why & b) != 0).sum()):8d}   only-this {int((why == b).sum()):8d}")
+wm = why.reshape(h, w)
+for k in range(8):
+    band = wm[k * h // 8:(k + 1) * h // 8]
+    print(f"  rows {k * h // 8:4d}-{(k + 1) * h // 8 - 1:4d}: rounding-only {int((band == 32).sum()):7d}  any {int((band != 0).sum()):7d}  of {band.size}")
 soa = orc.scene_to_soa(sc["elements"])
 want = orc.render_rgb64(soa, sc["background"], w, h)
 got8, f32 = r.render(w, h, flags=ptr_amd.MODE_F32_ONLY, want_f32=True)
