@@ -75,7 +75,8 @@ struct alignas(64) SphereP32 {
     float eb;
     // group 3: winner refinement (per-lane gather)
     float inv_r;          // 1 / radius
-    float hed;            // half the error bound of disc' = r^2 - |l x d|^2  (10 eps r |l| + 2 eps r^2)
+    float hed;            // half the error bound of disc' = r^2 - |l x d|^2  (10 eps r |l| + 2 eps r^2); NEGATIVE (same magnitude)
+                          //   when disc = b^2 - cc has the smaller bound for every ray (the origin close to a huge sphere)
     float refl, transp;   // Material.reflection / .transparency (extension modes only)
 };
 static_assert(sizeof(SphereP32) == 64, "SphereP32 layout");

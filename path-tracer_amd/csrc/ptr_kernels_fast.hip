@@ -309,7 +309,9 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
 #pragma unroll
                 for (int p = 0; p < PPL; p++) { m[p] = ballot(px[p].idx == w); rem[p] &= ~m[p]; }
                 arrive(W);
-                const float cc_w = W.g0.w, r2_w = W.g1.z, lnorm_w = W.g1.w, eb_w = W.g2.w, inv_r = W.g3.x, hed_w = W.g3.y;
+                const float cc_w = W.g0.w, r2_w = W.g1.z, lnorm_w = W.g1.w, eb_w = W.g2.w, inv_r = W.g3.x;
+                const bool form_b = __float_as_int(W.g3.y) < 0;        // wave-uniform (the host's flag: see SphereP32::hed)
+                const float hed_w = __int_as_float(__float_as_int(W.g3.y) & 0x7fffffff);
                 const bool outside = cc_w > 0.0f;          // wave-uniform: a scalar branch, not selects
 #pragma unroll
                 for (int p = 0; p < PPL; p++) {
@@ -318,11 +320,19 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
                         Shade& s = sh[p];
                         const F3 d = px[p].d;
                         const float b_w = fmaf(W.g0.z, d.z, fmaf(W.g0.y, d.y, W.g0.x * d.x));
-                        const F3 cr3{fmaf(W.g0.y, d.z, -(W.g0.z * d.y)), fmaf(W.g0.z, d.x, -(W.g0.x * d.z)), fmaf(W.g0.x, d.y, -(W.g0.y * d.x))};
-                        const float disc_w = fmaxf(r2_w - dot3(cr3, cr3), 1e-30f);
+                        float disc_w, herr_w;                          // the discriminant and half its error bound
+                        if (form_b) {
+                            // b^2 - cc: |error| <= (2|b| + eb) eb (of b) + 2 eps (b^2 + |cc|) (cc's own rounding, the fma's)
+                            disc_w = fmaxf(fmaf(b_w, b_w, -cc_w), 1e-30f);
+                            herr_w = 0.5001f * fmaf(fmaf(2.0f, fabsf(b_w), eb_w), eb_w, (2.0f * EPS) * fmaf(b_w, b_w, fabsf(cc_w)));
+                        } else {
+                            const F3 cr3{fmaf(W.g0.y, d.z, -(W.g0.z * d.y)), fmaf(W.g0.z, d.x, -(W.g0.x * d.z)), fmaf(W.g0.x, d.y, -(W.g0.y * d.x))};
+                            disc_w = fmaxf(r2_w - dot3(cr3, cr3), 1e-30f);
+                            herr_w = hed_w;
+                        }
                         const float s_w = rsq(disc_w);
                         const float thc_w = disc_w * s_w;
-                        const float et_w = fmaf(hed_w, s_w, eb_w);     // |error of (b + thc)|
+                        const float et_w = fmaf(herr_w, s_w, eb_w);    // |error of (b + thc)|
                         const float bt = b_w + thc_w;
                         const float rbt = rcp(bt);
                         float sg;

@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_many_kernel(RenderArgs a)
             const f2 e1 = pk_fma(b1, b1, splat(w));
             const bool px = e1.x >= 0.0f, py = e1.y >= 0.0f;
             if (!any_lane(px | py)) continue;                // wave-uniform
-            const Discp k = disc_pair<false>(l, splat(cc), splat(g1.z), splat(g3.y), splat(eb), d[q]);
+            const Discp k = disc_pair<false>(l, splat(cc), splat(g1.z), splat(fabsf(g3.y)), splat(eb), d[q]);
             const bool hx = px & (k.disc.x >= 0.0f) & (k.b.x >= 0.0f), hy = py & (k.disc.y >= 0.0f) & (k.b.y >= 0.0f);
             if constexpr (BOUNDS) {
                 const bool cx = (k.disc.x > k.err.x) & (k.b.x > eb), cy = (k.disc.y > k.err.y) & (k.b.y > eb);
@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_many_kernel(RenderArgs a)
         const f2 eb_w{gp32[i0].eb, gp32[i1].eb};
         const float2 c0 = *reinterpret_cast<const float2*>(&gp32[i0].inv_r), c1 = *reinterpret_cast<const float2*>(&gp32[i1].inv_r);
         const V3p lw{f2{a0.x, a1.x}, f2{a0.y, a1.y}, f2{a0.z, a1.z}};
-        const f2 ccw{a0.w, a1.w}, r2w{b0.x, b1.x}, lnw{b0.y, b1.y}, inv_r{c0.x, c1.x}, hedw{c0.y, c1.y};
+        const f2 ccw{a0.w, a1.w}, r2w{b0.x, b1.x}, lnw{b0.y, b1.y}, inv_r{c0.x, c1.x}, hedw{fabsf(c0.y), fabsf(c1.y)};      // (the sign is a flag for the few-sphere kernel)
         const Discp k = disc_pair<BOUNDS>(lw, ccw, r2w, hedw, eb_w, d[q]);
         const f2 dm = max2(k.disc, splat(1e-30f));
         const f2 s_w = rsq2(dm);
