@@ -251,7 +251,7 @@ def rc_reprojection_line(ptr_amd, torch, dist, rdr, world, rank, backend, librar
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)      # (the chip needs several launches to reach its clocks)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
