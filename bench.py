@@ -397,6 +397,7 @@ def main():
     if world > 1:
         try:
             step()
+            torch.cuda.synchronize()                 # (no torch collective while the library's own is still in flight)
             err = 0
         except ptr_amd.PtrError as e:                # the library's gather refused: every rank must learn of it
             print(f"rank {rank}: {e}", file=sys.stderr)

@@ -342,7 +342,7 @@ async function gpuTests() {
             Math.random = realRandom;
         }
     });
-    test('RenderCacheDriver: the resident frame loop leaves the same cache, grid and frames as the host walks (odd sizes, a frame that requests every pixel, a restart)', () => {
+    test('RenderCacheDriver: the resident frame loop leaves the same cache, grid and frames as the host walks (odd sizes, a frame that requests every pixel, a restart, other tunables)', () => {
         // no reference output exists at these sizes: the host form of the driver (bit-identical to the reference on the goldens
         // above) is the comparator; every array of the state is compared after every frame
         const idx = JSON.parse(fs.readFileSync(path.join(golden, 'rc', 'frames_index.json')));
@@ -351,11 +351,14 @@ async function gpuTests() {
         const realRandom = Math.random;
         const arrays = ['itemPixel', 'itemHit', 'itemAge', 'itemRgb', 'pixelElement', 'pixelDepth', 'pixelRgb', 'pixelPriority', 'pixelSample'];
         try {
-            for (const [w, h, ratio, nframes] of [[151, 97, 16, 7], [64, 33, 1, 4], [320, 200, 8, 6], [37, 2, 2, 5]]) {
+            for (const [w, h, ratio, nframes, tweak] of [[151, 97, 16, 7], [64, 33, 1, 4], [320, 200, 8, 6], [37, 2, 2, 5],
+                    [96, 40, 8, 5, { ageFactor: 2, interpolationZero: 5, interpolationRandom: 1, priorityMax: 100, depthThreshold: 60 }],
+                    [50, 50, 3, 4, { ageFactor: 3, priorityMax: 7 }]]) {
                 const drvs = [false, true].map(resident => {
                     const rt = new RayTracer(new Vector3(...desc.background), sceneFrom(desc), undefined, { mode: 'exact' });
                     const cam = new RcCamera(w, h), drv = new RenderCacheDriver(rt, cam, ratio, { resident });
                     drv.prepare(false);
+                    Object.assign(drv, tweak || {});                                     // the reference's tunables are plain fields
                     return { rt, cam, drv };
                 });
                 const px = w * h, a = new Uint32Array(px), b = new Uint32Array(px);
