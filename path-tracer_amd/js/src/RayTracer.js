@@ -26,8 +26,9 @@ import Plane from './Plane.js';
  * Extension modes (NOT reference behaviour: the reference stores Material.reflection/.transparency
  * and MAX_RAY_DEPTH but never reads them): renderFrame(w, h, {maxDepth, spp, seed}) follows
  * reflection/refraction rays to maxDepth (<= 16) and averages spp Philox-jittered samples per pixel.
- * Their specification is in include/ptr.h; mode 'exact' renders it in float64 bit for bit, every
- * other mode in float32.  render() itself always has the reference semantics.
+ * Their specification is in include/ptr.h; the default mode and 'exact' render it in float64 bit for bit,
+ * 'f32' renders it in float32 (the throughput form).  Scenes may also hold Plane elements and Phong
+ * materials (extensions too).  render() itself always has the reference semantics.
  */
 export default class RayTracer {
     constructor(backgroundColor, scene, camera, options = {}) {
