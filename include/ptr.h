@@ -281,7 +281,7 @@ int ptr_render_multi(ptr_ctx *const *ctxs, int n_ctxs, const ptr_params *p, uint
  * hipMalloc / hipFree / event creation, in any mode): the float32 kernels' re-trace queue, its counters and the work
  * counters live in a 32 MiB array that is part of the library's code object, one copy per GPU, held until the process
  * ends.  Limits and rules:
- *   - the hybrid mode needs 12 bytes of queue per pixel of the call's tiles: about 2.6 M pixels per call at most (one
+ *   - the hybrid mode needs 8 bytes of queue per pixel of the call's tiles (12 with more than 12 spheres): about 4 M pixels per call at most (one
  *     1920x1080 frame fits; width * scan_height * n_frames beyond that returns PTR_ERR_INVALID, nothing is launched);
  *   - the scene must already be resident: call ptr_sync() after the last ptr_set_scene* / ptr_set_background* /
  *     ptr_set_camera (the upload is what allocates); otherwise PTR_ERR_INVALID;

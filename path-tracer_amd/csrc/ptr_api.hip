@@ -590,12 +590,12 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
     while (n_queues * 2 <= PTR_MAX_QUEUES && n_queues * 8 <= n_blocks) n_queues *= 2;
     // a workgroup can queue at most PTR_BLOCK pixels; sub-queue s serves the workgroups b with (b & (n_queues - 1)) == s
     const uint64_t sub_capacity = (n_blocks + n_queues - 1) / n_queues * (uint64_t)(cpb * rpb);
-    const size_t queue_bytes = (size_t)(n_queues * sub_capacity) * 3 * sizeof(uint32_t);   // ids + 2 info words
+    const size_t queue_bytes = (size_t)(n_queues * sub_capacity) * (many ? 3 : 2) * sizeof(uint32_t);   // ids + 1 or 2 info words
     if (fixed_ws) {
         if (queue_bytes > NOALLOC_SCRATCH_BYTES - NOALLOC_QUEUE_OFFSET)
-            return fail(c, PTR_ERR_INVALID, "ptr_render_device_noalloc: this call needs a re-trace queue of %zu bytes (12 per "
-                                            "pixel of its tiles), the static array holds %zu: render fewer pixels per call "
-                                            "(about 2.6 M at most), or use ptr_render_device",
+            return fail(c, PTR_ERR_INVALID, "ptr_render_device_noalloc: this call needs a re-trace queue of %zu bytes (8 per "
+                                            "pixel of its tiles, 12 with more than 12 spheres), the static array holds %zu: render fewer pixels per call "
+                                            "(about 3.9 M at most), or use ptr_render_device",
                         queue_bytes, NOALLOC_SCRATCH_BYTES - NOALLOC_QUEUE_OFFSET);
     } else {
         PTR_TRY(grow(c, c->queue, queue_bytes));
@@ -604,6 +604,7 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
     const bool odd = !fixed_ws && (c->hybrid_calls & 1u) != 0;
     a.queue = fixed_ws ? reinterpret_cast<uint32_t*>(c->scratch_dev + NOALLOC_QUEUE_OFFSET) : static_cast<uint32_t*>(c->queue.ptr);
     a.qinfo = a.queue + n_queues * sub_capacity;
+    a.qinfo_packed = many ? 0u : 1u;
     a.queue_capacity = (uint32_t)sub_capacity;
     a.n_queues = (uint32_t)n_queues;
     a.counter = reinterpret_cast<uint32_t*>(words + (odd ? WORDS_COUNTER_B : WORDS_COUNTER_A));

@@ -169,7 +169,8 @@ struct RenderArgs {
     float*    out32f;                // nullable, n_frames * width * scan_height * 4
     uint32_t* queue;                 // hybrid: n_queues sub-queues of global pixel ids: full re-traces fill a
                                      //   sub-queue from its front, shading-only entries from its back
-    uint32_t* qinfo;                 // hybrid: 2 words per queue slot (nearest element, light verdict codes)
+    uint32_t* qinfo;                 // hybrid: per queue slot, nearest element and light verdict codes: one word (element << 24 | codes)
+    uint32_t  qinfo_packed;          //   from the few-sphere kernel (qinfo_packed 1), two words from the many-sphere kernel
     uint32_t* counter;               // hybrid: sub-queue fills (this call's set), PTR_COUNTER_STRIDE apart;
                                      //   word 0 = full re-traces, word 1 = shading-only entries
     uint32_t* counter_next;          // hybrid: the other set, zeroed by the re-trace for the next call

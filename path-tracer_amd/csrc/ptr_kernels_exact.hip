@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) retrace_exact_kernel(RenderArgs a)
     const uint32_t fill = a.counter[sub * PTR_COUNTER_STRIDE + kind];
     const uint32_t count = fill < a.queue_capacity ? fill : a.queue_capacity;
     const uint32_t* queue = a.queue + (uint64_t)sub * a.queue_capacity;
-    const uint32_t* qinfo = a.qinfo + 2 * (uint64_t)sub * a.queue_capacity;
+    const uint32_t* qinfo = a.qinfo + (a.qinfo_packed ? 1u : 2u) * (uint64_t)sub * a.queue_capacity;
     const uint64_t frame_px = (uint64_t)a.width * (uint64_t)a.scan_height;
     if (KIND == 0 && a.n >= PTR_WIDE_RETRACE_MIN) {
         // many spheres: one wave per queued pixel (trace_exact_wide), waves of all the sub-queue's workgroups take turns
@@ -350,7 +350,9 @@ __global__ void __launch_bounds__(PTR_BLOCK) retrace_exact_kernel(RenderArgs a)
         V3 d = primary_dir_exact(a.cam, x, global_y(a, row));
         V3 c;
         if constexpr (KIND == 1) {
-            const uint32_t element = qinfo[2 * slot], codes = qinfo[2 * slot + 1];
+            uint32_t element, codes;
+            if (a.qinfo_packed) { const uint32_t v = qinfo[slot]; element = v >> 24; codes = v & 0xffffffu; }
+            else { element = qinfo[2 * slot]; codes = qinfo[2 * slot + 1]; }
             if (element >= (uint32_t)a.n) continue;
             c = reshade_exact(fv, o, d, (int)element, codes);
         } else {

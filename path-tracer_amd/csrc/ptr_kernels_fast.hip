@@ -645,8 +645,7 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
                     if (q < a.queue_capacity) {
                         const uint64_t slot = (uint64_t)sub * a.queue_capacity + (a.queue_capacity - 1u - q);
                         a.queue[slot] = gid;
-                        a.qinfo[2 * slot] = (uint32_t)r.idx & 0xFFu;
-                        a.qinfo[2 * slot + 1] = ((uint32_t)r.idx >> 8) & 0x555555u;
+                        a.qinfo[slot] = (((uint32_t)r.idx & 0xFFu) << 24) | (((uint32_t)r.idx >> 8) & 0x555555u);
                     }
                 }
             }
