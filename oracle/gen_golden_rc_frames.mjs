@@ -53,6 +53,12 @@ async function main() {
               from: k => [0.5 * k, 0.25 * k, 0.4 * k], to: k => [0.2 * k, 0, -20] },
             { name: 'still_64x48', w: 64, h: 48, ratio: 8, frames: 4, seed: 22, from: () => [0, 1, 3], to: () => [0, 0, -20] },
             { name: 'turn_80x60', w: 80, h: 60, ratio: 4, frames: 4, seed: 23, from: k => [3 * k, 2, 6 - k], to: k => [-2 * k, 0, -20] },
+            // Driver.nextFrame1SPP (:117-128, what index.js calls when its `raytrace` switch is on, with ratio 1): gap filling,
+            // selection and trace only - no reprojection, no depth culling, no ageing
+            { name: 'onespp_48x32', w: 48, h: 32, ratio: 1, frames: 4, seed: 24, method: 'nextFrame1SPP',
+              from: k => [0.4 * k, 0.3, 2], to: k => [0, 0, -20] },
+            { name: 'onespp_ratio3_60x40', w: 60, h: 40, ratio: 3, frames: 5, seed: 25, method: 'nextFrame1SPP',
+              from: k => [0, 0.5 * k, 3 - 0.5 * k], to: k => [0.5 * k, 0, -20] },
         ];
         for (const cs of cases) {
             const scene = new Scene2();
@@ -68,7 +74,7 @@ async function main() {
                 rec.push(camera.from.x, camera.from.y, camera.from.z, ...camera.cam.matrixWorld.elements,
                          ...camera.cam.matrixWorldInverse.elements, ...camera.cam.projectionMatrix.elements,
                          ...camera.cam.projectionMatrixInverse.elements);
-                drv.nextFrame(k);
+                drv[cs.method || 'nextFrame'](k);
                 const st = drv.statistics;
                 rec.push(st.threshold === null ? NaN : st.threshold, st.requestFactor, st.candidates, st.requests, st.completeness,
                          st.totalPriority, drv.getCacheUsage());
@@ -80,7 +86,8 @@ async function main() {
             fs.writeFileSync(path.join(outDir, `frames_${cs.name}.f64`), Buffer.from(new Float64Array(rec).buffer));
             fs.writeFileSync(path.join(outDir, `frames_${cs.name}.u32`), Buffer.from(frames.buffer));
             index.cases[cs.name] = { file: `frames_${cs.name}.f64`, frames_file: `frames_${cs.name}.u32`, width: cs.w, height: cs.h,
-                                     ratio: cs.ratio, frames: cs.frames, seed: cs.seed, fov: 30, doubles_per_frame: 67 + 7 };
+                                     ratio: cs.ratio, frames: cs.frames, seed: cs.seed, fov: 30, doubles_per_frame: 67 + 7,
+                                     method: cs.method || 'nextFrame' };
         }
         fs.writeFileSync(path.join(outDir, 'frames_index.json'), JSON.stringify(index, null, 1));
     } finally {

@@ -223,6 +223,20 @@ export default class RenderCacheDriver {
         for (let i = 0; i < this.cacheSize; i++) this.itemAge[i] += this.ageFactor;      // age(ageFactor, cache)
     }
 
+    /**
+     * Driver.nextFrame1SPP (:117-128; what the reference's index.js calls when its `raytrace` switch is on, with ratio 1): gap
+     * filling, selection and trace alone - no reprojection, no depth culling, no ageing, the grid keeps its elements.  Host form
+     * (a resident cache is brought back first and goes up again with the next nextFrame()).
+     */
+    nextFrame1SPP(frameIndex) {
+        if (this.test) { this.initializeCacheWithEntireFrame(); return; }
+        if (this._onGpu) { this.syncToHost(); this._onGpu = false; }
+        if (frameIndex === 0) this.initializeCache();
+        this.shadeFrame(true);                                  // fillGaps
+        const requests = this.directSamples();
+        this.requestSamples(requests);
+    }
+
     /** Driver.reprojectFrame (:417-486) on the GPU; the border of the grid is not touched, as in the reference */
     reprojectFrame() {
         const cam = this.camera, w = cam.scope.x, h = cam.scope.y, st = this.stride;
@@ -239,10 +253,13 @@ export default class RenderCacheDriver {
     }
 
     /** Driver.depthCulling + Driver.fillGaps (:488-679) on the GPU */
-    shadeFrame() {
+    shadeFrame(fillOnly = false) {
         const w = this.camera.scope.x, h = this.camera.scope.y, st = this.stride;
+        // fillGaps alone: the culling step of the pass adds 10 age factors where depths disagree - with a factor of 0 it adds
+        // nothing, and the colour it copies to a pixel from its element is the colour that pixel already has (requestSamples
+        // stores both, Sample.js:68)
         const out = this.rc.shadeFrame(w, h, this.pixelElement, this.pixelDepth, this.itemAge, this.itemRgb,
-                                       { ageFactor: this.ageFactor, interpolationZero: this.interpolationZero,
+                                       { ageFactor: fillOnly ? 0 : this.ageFactor, interpolationZero: this.interpolationZero,
                                          interpolationRandom: this.interpolationRandom, priorityMax: this.priorityMax }, this.pixelRgb);
         for (let y = 1; y <= h; y++) {
             const a = y * st + 1, b = a + w;

@@ -301,7 +301,7 @@ async function gpuTests() {
         rc.dispose();
     });
     for (const resident of [false, true])
-    test(`RenderCacheDriver.nextFrame()${resident ? ', cache resident on the GPU' : ''}: whole render-cache frames, bit for bit (unmodified Driver.nextFrame goldens)`, () => {
+    test(`RenderCacheDriver.nextFrame()${resident ? ', cache resident on the GPU' : ''}: whole render-cache frames, bit for bit (unmodified Driver.nextFrame${resident ? '' : ' / nextFrame1SPP'} goldens)`, () => {
         // tests/golden/rc/frames_*: rendercache-js Driver.nextFrame over several frames with a moving camera and a seeded
         // Math.random (the generator is named in frames_index.json); inputs = the camera state per frame, outputs = frames + statistics
         const idx = JSON.parse(fs.readFileSync(path.join(golden, 'rc', 'frames_index.json')));
@@ -309,6 +309,8 @@ async function gpuTests() {
         const realRandom = Math.random;
         try {
             for (const [name, m] of Object.entries(idx.cases)) {
+                const method = m.method || 'nextFrame';
+                if (resident && method !== 'nextFrame') continue;            // (nextFrame1SPP is a host form)
                 const rec = f64(path.join('rc', m.file));
                 const fb = fs.readFileSync(path.join(golden, 'rc', m.frames_file));
                 const frames = new Uint32Array(fb.buffer, fb.byteOffset, fb.length / 4);
@@ -323,7 +325,7 @@ async function gpuTests() {
                     const o = k * m.doubles_per_frame;
                     cam.setView(rec.subarray(o, o + 3), rec.subarray(o + 3, o + 19), rec.subarray(o + 19, o + 35),
                                 rec.subarray(o + 35, o + 51), rec.subarray(o + 51, o + 67));
-                    drv.nextFrame(k);
+                    drv[method](k);
                     const st = drv.statistics, want = rec.subarray(o + 67, o + 74);
                     const tag = `${name} frame ${k}`;
                     assert.ok(Number.isNaN(want[0]) ? st.threshold === null : st.threshold === want[0], tag + ' threshold');

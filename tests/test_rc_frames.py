@@ -109,12 +109,14 @@ class HostCache:
             usage += 1 / self.ratio
 
 
-def frame_cases(golden_dir):
+def frame_cases(golden_dir, method="nextFrame"):
     with open(os.path.join(golden_dir, "rc", "frames_index.json")) as f:
         idx = json.load(f)
     with open(os.path.join(golden_dir, "rc", "index.json")) as f:
         scene = json.load(f)["scenes"]["rc_scene2"]
     for name, m in idx["cases"].items():
+        if m.get("method", "nextFrame") != method:                # (Driver.nextFrame1SPP: a host form, pinned through Node)
+            continue
         rec = np.fromfile(os.path.join(golden_dir, "rc", m["file"])).reshape(m["frames"], m["doubles_per_frame"])
         frames = np.fromfile(os.path.join(golden_dir, "rc", m["frames_file"]), dtype=np.uint32).reshape(m["frames"], 2, -1)
         yield name, m, scene, rec, frames
@@ -127,6 +129,12 @@ def test_golden_frames_are_complete(golden_dir):
         assert np.isfinite(rec[:, 68:74]).all(), name
         n += m["frames"]
     assert n == 13
+    n = 0
+    for name, m, scene, rec, frames in frame_cases(golden_dir, "nextFrame1SPP"):
+        assert frames.shape[2] == m["width"] * m["height"], name
+        assert np.isfinite(rec[:, 68:74]).all(), name
+        n += m["frames"]
+    assert n == 9
 
 
 @pytest.mark.gpu
