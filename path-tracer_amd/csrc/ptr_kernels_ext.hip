@@ -259,12 +259,14 @@ __device__ __forceinline__ bool any_lane_x(bool c) { return ballot(c) != 0ull; }
 // The stack of rays that wait (second children only: the reflection stays in registers).  Its entries have strictly
 // increasing depths from bottom to top, so max_depth entries per lane are enough.  The lowest PTR_EXT_LDS_ENTRIES of them
 // live in LDS, [entry][word][lane] (a lane's words are 256 bytes apart: every access is conflict-free), 2 560 bytes per entry
-// and wave: nothing of them ever reaches HBM.  Three entries (7.5 KB per wave) are what five waves per SIMD, the kernel's
-// register-bound occupancy, leave room for: a fourth costs a wave per SIMD (measured 14 % slower), a full-depth image two
-// (42 % slower).  The deeper entries (a chain of internal reflections inside a transparent sphere pushes one refracted ray
-// per bounce) go to a per-lane array in scratch memory: 23 B per pixel of the example frame at depth 5, none at depth <= 3.
+// and wave: nothing of them ever reaches HBM.  The deeper entries (a chain of internal reflections inside a transparent
+// sphere pushes one refracted ray per bounce) go to a per-lane array in scratch memory.  How many entries LDS holds is an
+// occupancy question: the kernel is bound by instruction issue AND by the latency of a wave, so waves per SIMD count.
+// Measured (1080p, example scene, depth 5, 256 frames): in the general kernel (94 VGPRs: 5 waves per SIMD) 3 entries, a
+// fourth costs a wave (14 % slower); as a kernel of its own (render_ext_f32_kernel, 70 VGPRs) 3 entries / 6 waves 14.1 ms,
+// 2 entries / 7 waves 12.7 ms, 2 entries / 8 waves (3 VGPR spills) 12.7 ms, 1 entry / 7 waves 13.0 ms, 4 entries 16.1 ms.
 #ifndef PTR_EXT_LDS_ENTRIES
-#define PTR_EXT_LDS_ENTRIES 3
+#define PTR_EXT_LDS_ENTRIES 2
 #endif
 struct RayStack {
     float* base;       // this lane's first word in LDS
@@ -461,53 +463,35 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     r0 = c0; r1 = c1;
 }
 
-template <typename T, bool STATS>
-__device__ __forceinline__ void render_ext_pixel(const RenderArgs& a, int x, int row, ExtCounts* k)
+// sample s of pixel (x, y): the camera ray's direction (RayTracer.js:171-172, jittered for spp > 1)
+template <typename T>
+__device__ __forceinline__ V<T> ext_camera_dir(const RenderArgs& a, int x, int y, int s)
 {
-    const int frame = blockIdx.z;
-    const int y = global_y(a, row);
-    SceneT<T> sc;
-    sc.fv = frame_view(a.scenes + (uint64_t)(a.first_frame + frame) * a.frame_stride);
-
     const T inv_w = T(a.cam.inv_w), inv_h = T(a.cam.inv_h), angle = T(a.cam.angle), aspect = T(a.cam.aspect);
-    // float32 works camera-relative: the ray starts at 0 there
-    const V<T> origin = sizeof(T) == 8 ? V<T>{T(a.cam.org[0]), T(a.cam.org[1]), T(a.cam.org[2])} : V<T>{0, 0, 0};
-    V<T> sum{0, 0, 0};
-    for (int s = 0; s < a.spp; s++) {
-        T px = T(x) + T(0.5), py = T(y) + T(0.5);
-        if (a.spp > 1) {
-            uint32_t r0, r1;
-            philox4x32_10((uint32_t)x, (uint32_t)y, (uint32_t)s, 0u, a.seed, 0x50545221u, r0, r1);
-            px = T(x) + T((double(r0) + 0.5) / 4294967296.0);
-            py = T(y) + T((double(r1) + 0.5) / 4294967296.0);
-        }
-        const T xx = (2 * (px * inv_w) - 1) * angle * aspect;      // RayTracer.js:171-172
-        const T yy = (1 - 2 * (py * inv_h)) * angle;
-        V<T> d;
-        if (a.cam.general) {
-            d.x = xx * T(a.cam.right[0]) + yy * T(a.cam.up[0]) + T(a.cam.fwd[0]);
-            d.y = xx * T(a.cam.right[1]) + yy * T(a.cam.up[1]) + T(a.cam.fwd[1]);
-            d.z = xx * T(a.cam.right[2]) + yy * T(a.cam.up[2]) + T(a.cam.fwd[2]);
-        } else {
-            d = V<T>{xx, yy, T(-1)};
-        }
-        normalize_v(d);
-        xcount<STATS>(k, XT_CAMERA);
-        V<T> c;
-        bool done = false;
-        if constexpr (sizeof(T) == 4 && !STATS) if (sc.fv.h->n_planes == 0u && sc.fv.h->has_phong == 0u) {
-            // (scenes with planes or Phong terms take the general form below in float32 too)
-            done = true;
-            const unsigned char* block = a.scenes + (uint64_t)(a.first_frame + frame) * a.frame_stride;
-            __shared__ float ext_lds[PTR_EXT_LDS_ENTRIES * 640];          // (the float32 form runs one wave per workgroup)
-            RayStack st;
-            st.base = ext_lds + (threadIdx.x & 63);
-            const V<float> cf = trace_ext_f32(st, block, a, V<float>{0, 0, 0}, V<float>{(float)d.x, (float)d.y, (float)d.z}, a.max_depth);
-            c = V<T>{T(cf.x), T(cf.y), T(cf.z)};
-        }
-        if (!done) c = trace_ext<T, STATS>(sc, origin, d, a.max_depth, k);
-        sum.x += c.x; sum.y += c.y; sum.z += c.z;
+    T px = T(x) + T(0.5), py = T(y) + T(0.5);
+    if (a.spp > 1) {
+        uint32_t r0, r1;
+        philox4x32_10((uint32_t)x, (uint32_t)y, (uint32_t)s, 0u, a.seed, 0x50545221u, r0, r1);
+        px = T(x) + T((double(r0) + 0.5) / 4294967296.0);
+        py = T(y) + T((double(r1) + 0.5) / 4294967296.0);
     }
+    const T xx = (2 * (px * inv_w) - 1) * angle * aspect;      // RayTracer.js:171-172
+    const T yy = (1 - 2 * (py * inv_h)) * angle;
+    V<T> d;
+    if (a.cam.general) {
+        d.x = xx * T(a.cam.right[0]) + yy * T(a.cam.up[0]) + T(a.cam.fwd[0]);
+        d.y = xx * T(a.cam.right[1]) + yy * T(a.cam.up[1]) + T(a.cam.fwd[1]);
+        d.z = xx * T(a.cam.right[2]) + yy * T(a.cam.up[2]) + T(a.cam.fwd[2]);
+    } else {
+        d = V<T>{xx, yy, T(-1)};
+    }
+    normalize_v(d);
+    return d;
+}
+
+template <typename T>
+__device__ __forceinline__ void ext_store(const RenderArgs& a, int frame, int x, int row, V<T> sum)
+{
     if (a.spp > 1) { const T k = T(a.spp); sum.x /= k; sum.y /= k; sum.z /= k; }
     const uint64_t at = frame * a.out_frame_stride + (uint64_t)a.width * row + x;
     a.out8[at] = pack_js((double)sum.x, (double)sum.y, (double)sum.z);
@@ -515,6 +499,26 @@ __device__ __forceinline__ void render_ext_pixel(const RenderArgs& a, int x, int
         float* p = a.out32f + 4 * at;
         p[0] = (float)sum.x; p[1] = (float)sum.y; p[2] = (float)sum.z; p[3] = 1.0f;
     }
+}
+
+// (float32 here is the general form: scenes with planes or Phong terms; spheres alone take render_ext_f32_kernel)
+template <typename T, bool STATS>
+__device__ __forceinline__ void render_ext_pixel(const RenderArgs& a, int x, int row, ExtCounts* k)
+{
+    const int frame = blockIdx.z;
+    const int y = global_y(a, row);
+    SceneT<T> sc;
+    sc.fv = frame_view(a.scenes + (uint64_t)(a.first_frame + frame) * a.frame_stride);
+    // float32 works camera-relative: the ray starts at 0 there
+    const V<T> origin = sizeof(T) == 8 ? V<T>{T(a.cam.org[0]), T(a.cam.org[1]), T(a.cam.org[2])} : V<T>{0, 0, 0};
+    V<T> sum{0, 0, 0};
+    for (int s = 0; s < a.spp; s++) {
+        const V<T> d = ext_camera_dir<T>(a, x, y, s);
+        xcount<STATS>(k, XT_CAMERA);
+        const V<T> c = trace_ext<T, STATS>(sc, origin, d, a.max_depth, k);
+        sum.x += c.x; sum.y += c.y; sum.z += c.z;
+    }
+    ext_store<T>(a, frame, x, row, sum);
 }
 
 template <typename T, bool STATS>
@@ -539,7 +543,36 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_ext_kernel(RenderArgs a)
     }
 }
 
-hipError_t launch_render_ext(const RenderArgs& a, int n_frames, bool f64, bool stats, hipStream_t s)
+// The float32 form on a scene of spheres without Phong terms, as a kernel of its own: the general float32 path (planes,
+// Phong terms; trace_ext<float>) in the same kernel costs it 19 VGPRs it never uses.
+#ifndef PTR_EXT_WAVES
+#define PTR_EXT_WAVES 7
+#endif
+#if PTR_EXT_WAVES > 0
+#define PTR_EXT_OCC __attribute__((amdgpu_waves_per_eu(PTR_EXT_WAVES, PTR_EXT_WAVES)))
+#else
+#define PTR_EXT_OCC
+#endif
+__global__ void __launch_bounds__(64) PTR_EXT_OCC render_ext_f32_kernel(RenderArgs a)
+{
+    const int lane = threadIdx.x;
+    const int x = blockIdx.x * 8 + (lane & 7), row = blockIdx.y * PTR_TILE_H + (lane >> 3), frame = blockIdx.z;
+    if (x >= a.width || row >= a.scan_height) return;
+    const unsigned char* block = a.scenes + (uint64_t)(a.first_frame + frame) * a.frame_stride;
+    __shared__ float ext_lds[PTR_EXT_LDS_ENTRIES * 640];
+    RayStack st;
+    st.base = ext_lds + lane;
+    const int y = global_y(a, row);
+    V<float> sum{0, 0, 0};
+    for (int s = 0; s < a.spp; s++) {
+        const V<float> d = ext_camera_dir<float>(a, x, y, s);
+        const V<float> c = trace_ext_f32(st, block, a, V<float>{0, 0, 0}, d, a.max_depth);
+        sum.x += c.x; sum.y += c.y; sum.z += c.z;
+    }
+    ext_store<float>(a, frame, x, row, sum);
+}
+
+hipError_t launch_render_ext(const RenderArgs& a, int n_frames, bool f64, bool stats, bool spheres_only, hipStream_t s)
 {
     dim3 grid((a.width + PTR_TILE_W - 1) / PTR_TILE_W, (a.scan_height + PTR_TILE_H - 1) / PTR_TILE_H, n_frames);
     if (stats) hipLaunchKernelGGL((render_ext_kernel<double, true>), grid, dim3(PTR_BLOCK), 0, s, a);
@@ -548,7 +581,8 @@ hipError_t launch_render_ext(const RenderArgs& a, int n_frames, bool f64, bool s
         // one wave per workgroup: the waves' run times differ by an order of magnitude (a tile on a transparent sphere
         // expands a tree of rays), and a one-wave workgroup starts wherever a slot is free
         const dim3 grid1((a.width + 7) / 8, grid.y, n_frames);
-        hipLaunchKernelGGL((render_ext_kernel<float, false>), grid1, dim3(64), 0, s, a);
+        if (spheres_only) hipLaunchKernelGGL(render_ext_f32_kernel, grid1, dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((render_ext_kernel<float, false>), grid1, dim3(64), 0, s, a);
     }
     return hipGetLastError();
 }
