@@ -1,4 +1,4 @@
-"""Times the float32 extension kernel (PTR_MODE_F32_ONLY) on one MI355X and prints a hash of what it drew, so that two builds
+"""Times the float32 extension kernel (PTR_MODE_F32_ONLY; PTR_AB_MODE=exact: the float64 one) on one MI355X and prints a hash of what it drew, so that two builds
 of the library can be compared on one box:  python tools/ext_ab.py  (the library in the tree);
 PTR_AB_LIB=path/to/other.so python tools/ext_ab.py  (another build)."""
 import hashlib, json, os, sys, time
@@ -10,9 +10,11 @@ if os.environ.get("PTR_AB_LIB"):
 from ptr_amd import synthetic as syn
 from bench import example1_soa
 
+MODE = ptr_amd.MODE_EXACT_F64 if os.environ.get("PTR_AB_MODE") == "exact" else ptr_amd.MODE_F32_ONLY
+
 def run(r, name, w, h, depth, spp, frames, reps):
     out = torch.zeros((frames, h, w), dtype=torch.int32, device="cuda")
-    p = r.params(w, h, flags=ptr_amd.MODE_F32_ONLY, max_depth=depth, spp=spp, seed=0x5EED1234)
+    p = r.params(w, h, flags=MODE, max_depth=depth, spp=spp, seed=0x5EED1234)
     s = torch.cuda.current_stream().cuda_stream
     for _ in range(2):
         r.render_device(p, 0, frames, out.data_ptr(), stream=s)
@@ -27,7 +29,7 @@ def run(r, name, w, h, depth, spp, frames, reps):
 
 r = ptr_amd.Renderer(0)
 r.set_scene(np.ascontiguousarray(np.broadcast_to(example1_soa(), (256, 12, 7)))); r.set_background([2.0, 2.0, 2.0])
-run(r, "example1 1080p depth5 x256", 1920, 1080, 5, 1, 256, 5)
+run(r, "example1 1080p depth5 x256", 1920, 1080, 5, 1, 256 if MODE == ptr_amd.MODE_F32_ONLY else 64, 5)
 run(r, "example1 1080p depth3 x64", 1920, 1080, 3, 1, 64, 5)
 run(r, "example1 640x480 depth5 x1", 640, 480, 5, 1, 1, 20)
 r.set_scene(syn.config3_scene()); r.set_background(syn.BACKGROUND)
