@@ -503,7 +503,7 @@ def main():
                   "value": round(rays5 * frames_total * n5 / dt5 / 1e6, 1), "unit": "Mrays/s",
                   "ms_per_step": round(dt5 / n5 * 1e3, 4), "rays_per_frame": rays5,
                   "camera_rays": st5["primary"], "secondary_rays": st5["secondary"], "shadow_rays": st5["shadow_rays"],
-                  "roofline": {"bound": "valu", "kernel": "render_ext_kernel<float>", "achieved": round(ach5, 3),
+                  "roofline": {"bound": "valu", "kernel": "render_ext_f32_kernel", "achieved": round(ach5, 3),
                                "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": round(ach5 / PEAK_FP32_VALU_TFLOPS, 4),
                                "kernel_ms": round(float(np.mean(k5)), 4), "algorithmic_flops_per_launch": int(flops5),
                                "traffic": None,
