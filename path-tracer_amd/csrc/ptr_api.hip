@@ -532,6 +532,13 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
         a.cull_on = (rows_consecutive && sn < 0.5) ? 1 : 0;
         a.cull_sin = (float)(sn * (1.0 + 1e-6));
         a.cull_cos = (float)(std::sqrt(std::fmax(0.0, 1.0 - sn * sn)) * (1.0 - 1e-6));
+        // (the bounce-loop kernel's waves cover 8 x 8 pixels, and a jittered sample lies anywhere in its pixel: 4 pixels each way)
+        const double rho_x = 4.0 * std::fabs((double)a.camf.sx) * std::sqrt(R[0] * R[0] + R[1] * R[1] + R[2] * R[2]) +
+                             4.0 * std::fabs((double)a.camf.sy) * std::sqrt(U[0] * U[0] + U[1] * U[1] + U[2] * U[2]);
+        const double snx = dmin > 0 ? 1.02 * rho_x / dmin + 1e-6 : 2.0;
+        a.ext_cull_on = (rows_consecutive && snx < 0.5) ? 1 : 0;
+        a.ext_cull_sin = (float)(snx * (1.0 + 1e-6));
+        a.ext_cull_cos = (float)(std::sqrt(std::fmax(0.0, 1.0 - snx * snx)) * (1.0 - 1e-6));
         // The float32 error budget of the hit tests (PR_RELB: 10 eps for b = l.d) counts on a camera ray that is good to
         // about one eps, which is what xx R + yy U + F gives while its terms are of the size of the sum: the direction's
         // relative error grows like g = (|xx|max |R| + |yy|max |U| + |F|) / dmin (1.7 for the reference camera at 16:9;

@@ -165,6 +165,8 @@ struct RenderArgs {
     CameraF32  camf;
     float     cull_cos, cull_sin;    // float32 kernel: every ray of a wave's (8 PPL) x 8 tile is within this angle of the
     int32_t   cull_on;               //   tile's centre ray (bound, padded); cull_on 0: tiles are not contiguous, no culling
+    float     ext_cull_cos, ext_cull_sin;   // the same for the 8 x 8 tiles of the float32 bounce-loop kernel, jittered samples included
+    int32_t   ext_cull_on;
     uint32_t* out8;                  // n_frames * width * scan_height
     float*    out32f;                // nullable, n_frames * width * scan_height * 4
     uint32_t* queue;                 // hybrid: n_queues sub-queues of global pixel ids: full re-traces fill a

@@ -292,8 +292,10 @@ struct RayStack {
     }
 };
 
+// cand0: the spheres a camera ray of this wave's tile can reach at all (bit i; all ones: no such knowledge)
 template <typename Stack>
-__device__ V<float> trace_ext_f32(Stack& stack, const unsigned char* block, const RenderArgs& a, V<float> o0, V<float> d0, int max_depth)
+__device__ V<float> trace_ext_f32(Stack& stack, const unsigned char* block, const RenderArgs& a, V<float> o0, V<float> d0, int max_depth,
+                                  unsigned long long cand0 = ~0ull)
 {
     const ConstHeader hdr = (ConstHeader)(uintptr_t)block;
     const ConstF4 recv0 = (ConstF4)(uintptr_t)(block + a.off_p32);      // the same table through loads that stay where they are written
@@ -311,6 +313,7 @@ __device__ V<float> trace_ext_f32(Stack& stack, const unsigned char* block, cons
     int top = 0;
     ExtRay<float> r{o0, d0, V<float>{1, 1, 1}, 0};
     bool have = true;
+    bool first = true;                                           // the camera ray: all lanes take the loop's first pass together
     float ax = 0.0f, ay = 0.0f, az = 0.0f;
     while (have || top > 0) {
         if (!have) r = stack.pop(--top);
@@ -336,7 +339,15 @@ __device__ V<float> trace_ext_f32(Stack& stack, const unsigned char* block, cons
                     e = nearer ? i : e;
                 }
             };
-            if (n > 0) {
+            if (cand0 != ~0ull && __builtin_amdgcn_readfirstlane((int)first) != 0) {
+                // the camera ray: only the spheres the tile's cone reaches (a culled sphere is a certain miss for every lane)
+                for (unsigned long long c = cand0; c != 0ull; c &= c - 1ull) {
+                    const int i = __builtin_ctzll(c);
+                    const P32G q = load_p32g(recv0 + 4u * (unsigned)i);
+                    arrive(q);
+                    test(q, i);
+                }
+            } else if (n > 0) {
                 ConstF4 rp = recv0;
                 P32G A = load_p32g(rp), B;
                 int i = 0;
@@ -347,6 +358,7 @@ __device__ V<float> trace_ext_f32(Stack& stack, const unsigned char* block, cons
                     if (++i >= n) break;
                 }
             }
+            first = false;
         }
         if (e < 0) {
             ax = fmaf(r.w.x, bgx, ax); ay = fmaf(r.w.y, bgy, ay); az = fmaf(r.w.z, bgz, az);
@@ -557,16 +569,38 @@ __global__ void __launch_bounds__(64) PTR_EXT_OCC render_ext_f32_kernel(RenderAr
 {
     const int lane = threadIdx.x;
     const int x = blockIdx.x * 8 + (lane & 7), row = blockIdx.y * PTR_TILE_H + (lane >> 3), frame = blockIdx.z;
-    if (x >= a.width || row >= a.scan_height) return;
     const unsigned char* block = a.scenes + (uint64_t)(a.first_frame + frame) * a.frame_stride;
     __shared__ float ext_lds[PTR_EXT_LDS_ENTRIES * 640];
     RayStack st;
     st.base = ext_lds + lane;
+    // Which spheres can a camera ray of this wave's 8 x 8 tile reach?  The tile's rays lie in a cone around its centre ray
+    // (half-angle bound from the host); lane i decides for sphere i from its CullRec (see ptr_kernels_fast.hip), and the
+    // camera ray's pass over the spheres visits the set bits only: a floor or sky tile tests one sphere instead of all.
+    unsigned long long cand = ~0ull;
+    if (a.ext_cull_on && a.n <= 64) {
+        const CullRec* gcull = reinterpret_cast<const CullRec*>(block + a.off_cull);
+        const int li = lane < a.n ? lane : a.n;                  // (record n: zeros)
+        const float4 g0 = *reinterpret_cast<const float4*>(&gcull[li].lx);   // lx ly lz s
+        const float2 g1 = *reinterpret_cast<const float2*>(&gcull[li].re);   // re c
+        const float xc = fmaf((float)(blockIdx.x * 8 + 4), a.camf.sx, a.camf.ox);
+        const float yc = fmaf((float)(global_y(a, blockIdx.y * PTR_TILE_H) + PTR_TILE_H / 2), a.camf.sy, a.camf.oy);   // (consecutive rows)
+        V<float> dc{xc, yc, -1.0f};
+        if (a.cam.general) {
+            dc.x = fmaf(xc, a.camf.right[0], fmaf(yc, a.camf.up[0], a.camf.fwd[0]));
+            dc.y = fmaf(xc, a.camf.right[1], fmaf(yc, a.camf.up[1], a.camf.fwd[1]));
+            dc.z = fmaf(xc, a.camf.right[2], fmaf(yc, a.camf.up[2], a.camf.fwd[2]));
+        }
+        const float inv = rsq(fmaf(dc.z, dc.z, fmaf(dc.y, dc.y, dc.x * dc.x)));
+        const float bc = fmaf(g0.z, dc.z, fmaf(g0.y, dc.y, g0.x * dc.x)) * inv;
+        const float K = fmaf(a.ext_cull_cos, g0.w, -fmaf(a.ext_cull_sin, g1.x, g1.y));
+        cand = ballot(bc >= K) & (a.n >= 64 ? ~0ull : (1ull << a.n) - 1ull);
+    }
     const int y = global_y(a, row);
+    if (x >= a.width || row >= a.scan_height) return;            // (after the culling step: every lane speaks for a sphere there)
     V<float> sum{0, 0, 0};
     for (int s = 0; s < a.spp; s++) {
         const V<float> d = ext_camera_dir<float>(a, x, y, s);
-        const V<float> c = trace_ext_f32(st, block, a, V<float>{0, 0, 0}, d, a.max_depth);
+        const V<float> c = trace_ext_f32(st, block, a, V<float>{0, 0, 0}, d, a.max_depth, cand);
         sum.x += c.x; sum.y += c.y; sum.z += c.z;
     }
     ext_store<float>(a, frame, x, row, sum);
