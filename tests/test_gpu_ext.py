@@ -236,3 +236,16 @@ def test_rejections(rdr, scenes):
         with pytest.raises(ptr_amd.PtrError) as e:
             rdr.render(64, 48, **kw)
         assert e.value.code == code, kw
+
+
+def test_random_scenes_against_the_specification():
+    """tools/soak_ext.py, bounded: 120 random scenes (1-39 spheres, reflective / transparent / nested / a huge floor; depth 0-7,
+    1-5 samples, odd frame sizes): the float64 kernel (default mode) equals the CPU specification on every pixel.  The float32
+    form on the same scenes: at most 0.05 % of the pixels beyond 1/255 (measured over 4 000 scenes: 0.0086 %)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import soak_ext
+    px, bad, beyond, worst = soak_ext.soak(120, 11, verbose=False)
+    print(f"{px} pixels: float64 differs on {bad}; float32 beyond 1/255 on {beyond}, worst PSNR {worst:.1f} dB")
+    assert bad == 0
+    assert beyond <= 5e-4 * px
