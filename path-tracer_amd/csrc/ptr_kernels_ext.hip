@@ -329,7 +329,8 @@ __device__ V<float> trace_ext_f32(Stack& stack, const unsigned char* block, cons
                 const float b = fmaf(lz, r.d.z, fmaf(ly, r.d.y, lx * r.d.x));
                 const float ll = fmaf(lz, lz, fmaf(ly, ly, lx * lx));
                 const float disc = fmaf(b, b, q.g1.z - ll);                   // radius2 - d2 (Sphere.js:21-27)
-                const unsigned long long hit_m = ballot(b >= 0.0f) & ballot(disc >= 0.0f);
+                // (b >= 0 and disc >= 0 as ONE compare: a compare's mask can be branched on directly, the AND of two cannot)
+                const unsigned long long hit_m = ballot(fmin_raw(b, disc) >= 0.0f);
                 if (hit_m != 0ull) {
                     const float thc = disc * rsq(fmax_raw(disc, 1e-30f));
                     float t = b - thc;
@@ -348,15 +349,17 @@ __device__ V<float> trace_ext_f32(Stack& stack, const unsigned char* block, cons
                     test(q, i);
                 }
             } else if (n > 0) {
+                // (pairs without a check between them, an odd last record after the loop: the loop's bookkeeping is scalar
+                // instructions that cost issue slots like any other)
                 ConstF4 rp = recv0;
                 P32G A = load_p32g(rp), B;
                 int i = 0;
-                for (;;) {
-                    rp += 4; arrive(A); B = load_p32g(rp); test(A, i);
-                    if (++i >= n) break;
-                    rp += 4; arrive(B); A = load_p32g(rp); test(B, i);
-                    if (++i >= n) break;
+                for (; i + 1 < n; i += 2) {
+                    arrive(A); B = load_p32g(rp + 4); test(A, i);
+                    arrive(B); A = load_p32g(rp + 8); test(B, i + 1);
+                    rp += 8;
                 }
+                if (i < n) { arrive(A); test(A, i); }
             }
             first = false;
         }
@@ -436,7 +439,7 @@ __device__ V<float> trace_ext_f32(Stack& stack, const unsigned char* block, cons
                         const float b = fmaf(lz, Lz, fmaf(ly, Ly, lx * Lx));
                         const float ll = fmaf(lz, lz, fmaf(ly, ly, lx * lx));
                         const float disc = fmaf(b, b, q.g1.z - ll);
-                        open_m &= ~(ballot(b >= 0.0f) & ballot(disc >= 0.0f));   // any hit blocks; distance ignored (F7)
+                        open_m &= ~ballot(fmin_raw(b, disc) >= 0.0f);            // any hit blocks; distance ignored (F7)
                     };
                     // pre-filter records one ahead, in two buffers that swap roles (rows are padded past n)
                     ConstF4 pp = pairs;
