@@ -330,7 +330,7 @@ __device__ V<float> trace_ext_f32(Stack& stack, const unsigned char* block, cons
                 const float ll = fmaf(lz, lz, fmaf(ly, ly, lx * lx));
                 const float disc = fmaf(b, b, q.g1.z - ll);                   // radius2 - d2 (Sphere.js:21-27)
                 // (b >= 0 and disc >= 0 as ONE compare: a compare's mask can be branched on directly, the AND of two cannot)
-                const unsigned long long hit_m = ballot(fmin_raw(b, disc) >= 0.0f);
+                const unsigned long long hit_m = ballot(fminf(b, disc) >= 0.0f);
                 if (hit_m != 0ull) {
                     const float thc = disc * rsq(fmax_raw(disc, 1e-30f));
                     float t = b - thc;
@@ -439,7 +439,7 @@ __device__ V<float> trace_ext_f32(Stack& stack, const unsigned char* block, cons
                         const float b = fmaf(lz, Lz, fmaf(ly, Ly, lx * Lx));
                         const float ll = fmaf(lz, lz, fmaf(ly, ly, lx * lx));
                         const float disc = fmaf(b, b, q.g1.z - ll);
-                        open_m &= ~ballot(fmin_raw(b, disc) >= 0.0f);            // any hit blocks; distance ignored (F7)
+                        open_m &= ~ballot(fminf(b, disc) >= 0.0f);            // any hit blocks; distance ignored (F7)
                     };
                     // pre-filter records one ahead, in two buffers that swap roles (rows are padded past n)
                     ConstF4 pp = pairs;
