@@ -169,7 +169,7 @@ void default_camera(ptr_camera& cam)
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct BlockLayout {
-    uint32_t off_g64, off_m64, off_p32, off_m32, off_lights, off_pairs, off_lrec, off_cull;
+    uint32_t off_g64, off_m64, off_p32, off_m32, off_lights, off_pairs, off_lrec, off_cull, off_x4;
     uint32_t off_pl64, off_plm64, off_pl32, off_plm32, off_ph64, off_ph32;
     size_t   bytes;
 };
@@ -194,6 +194,10 @@ BlockLayout block_layout(int n, int np = 0, bool phong = false)
     L.off_lrec = (uint32_t)o;   o += sizeof(LightRec) * ((size_t)n + 1);
     o = align_up(o, 64);
     L.off_cull = (uint32_t)o;   o += sizeof(CullRec) * ((size_t)n + 1);
+    // the bounce-loop kernel's view of the spheres: lx ly lz r2, 16 bytes each, read four at a time; padded with records no
+    // ray hits (r2 = -1) to a multiple of four + four for the look-ahead
+    o = align_up(o, 64);
+    L.off_x4 = (uint32_t)o;     o += 16 * (align_up((size_t)n, 4) + 4);
     // planes and Phong terms (extension modes; empty otherwise)
     o = align_up(o, 64);
     L.off_pl64 = (uint32_t)o;   o += sizeof(PlaneG64) * (size_t)np;
@@ -312,6 +316,15 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
     {
         const size_t row = (size_t)(n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS);
         for (int j = 0; j < pair_stride(n); j++) pairs[row * (size_t)pair_stride(n) + (size_t)j] = PairQ{0, 0, 0, -1.0f};
+    }
+    {
+        float* x4 = reinterpret_cast<float*>(dst + L.off_x4);
+        const size_t padded = align_up((size_t)n, 4) + 4;
+        for (size_t i = 0; i < padded; i++) {
+            const bool real = i < (size_t)n;
+            x4[4 * i] = real ? p32[i].lx : 0.0f; x4[4 * i + 1] = real ? p32[i].ly : 0.0f; x4[4 * i + 2] = real ? p32[i].lz : 0.0f;
+            x4[4 * i + 3] = real ? p32[i].r2 : -1.0f;
+        }
     }
     CullRec* cull = reinterpret_cast<CullRec*>(dst + L.off_cull);        // (record n: zeros, read by the lanes past n)
     for (int i = 0; i < n; i++) {
@@ -490,7 +503,7 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
     a.frame_stride = c->frame_stride;
     {
         const BlockLayout L = block_layout(c->n_spheres);
-        a.off_p32 = L.off_p32; a.off_m32 = L.off_m32; a.off_lights = L.off_lights; a.off_pairs = L.off_pairs; a.off_lrec = L.off_lrec; a.off_cull = L.off_cull;
+        a.off_p32 = L.off_p32; a.off_m32 = L.off_m32; a.off_lights = L.off_lights; a.off_pairs = L.off_pairs; a.off_lrec = L.off_lrec; a.off_cull = L.off_cull; a.off_x4 = L.off_x4;
         a.n = c->n_spheres;
     }
     a.first_frame = first_frame;

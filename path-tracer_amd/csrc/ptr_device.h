@@ -154,7 +154,7 @@ struct RenderArgs {
     const unsigned char* scenes;     // frame blocks, frame_stride bytes apart
     uint64_t  frame_stride;
     uint32_t  off_p32, off_m32, off_lights, off_pairs;   // byte offsets inside a frame block (same for every frame)
-    uint32_t  off_lrec, off_cull;
+    uint32_t  off_lrec, off_cull, off_x4;
     int32_t   n;                     // elements per frame
     int32_t   first_frame, n_frames;
     int32_t   width, height, start_y, scan_height;

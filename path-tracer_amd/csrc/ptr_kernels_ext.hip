@@ -299,6 +299,7 @@ __device__ V<float> trace_ext_f32(Stack& stack, const unsigned char* block, cons
 {
     const ConstHeader hdr = (ConstHeader)(uintptr_t)block;
     const ConstF4 recv0 = (ConstF4)(uintptr_t)(block + a.off_p32);      // the same table through loads that stay where they are written
+    const ConstF4 x4v0 = (ConstF4)(uintptr_t)(block + a.off_x4);        // lx ly lz r2 per sphere, padded with never-hit records
     const ConstF4 pairv0 = (ConstF4)(uintptr_t)(block + a.off_pairs);
     const ConstF4 lrec0 = (ConstF4)(uintptr_t)(block + a.off_lrec);
     const SphereP32* gp32 = reinterpret_cast<const SphereP32*>(block + a.off_p32);
@@ -322,13 +323,15 @@ __device__ V<float> trace_ext_f32(Stack& stack, const unsigned char* block, cons
         float tnear = (float)PTR_INFINITY;
         int e = -1;
         {
-            // Two record buffers in SGPRs that swap roles: record i + 1 is requested before record i is used (the table
-            // ends with zero records, so the look-ahead needs no special case), and hit / miss is decided on lane masks.
-            auto test = [&](const P32G& q, int i) {
-                const float lx = q.g0.x - r.o.x, ly = q.g0.y - r.o.y, lz = q.g0.z - r.o.z;
+            // The spheres come four at a time (lx ly lz r2 of each, one s_load_dwordx16 from the compact table), in two
+            // buffers that swap roles: the next four are requested before these four are used, and the wave waits for scalar
+            // data once per four tests instead of once per test (scalar loads return out of order: a wait is for all of them).
+            // Hit / miss is decided on lane masks.
+            auto test = [&](const f4 q, int i) {
+                const float lx = q.x - r.o.x, ly = q.y - r.o.y, lz = q.z - r.o.z;
                 const float b = fmaf(lz, r.d.z, fmaf(ly, r.d.y, lx * r.d.x));
                 const float ll = fmaf(lz, lz, fmaf(ly, ly, lx * lx));
-                const float disc = fmaf(b, b, q.g1.z - ll);                   // radius2 - d2 (Sphere.js:21-27)
+                const float disc = fmaf(b, b, q.w - ll);                      // radius2 - d2 (Sphere.js:21-27)
                 // (b >= 0 and disc >= 0 as ONE compare: a compare's mask can be branched on directly, the AND of two cannot)
                 const unsigned long long hit_m = ballot(fminf(b, disc) >= 0.0f);
                 if (hit_m != 0ull) {
@@ -340,26 +343,30 @@ __device__ V<float> trace_ext_f32(Stack& stack, const unsigned char* block, cons
                     e = nearer ? i : e;
                 }
             };
+            auto test4 = [&](const P32W& q, int i) {
+                test(q.g0, i);
+                if (i + 1 < n) test(q.g1, i + 1);
+                if (i + 2 < n) test(q.g2, i + 2);
+                if (i + 3 < n) test(q.g3, i + 3);
+            };
             if (cand0 != ~0ull && __builtin_amdgcn_readfirstlane((int)first) != 0) {
                 // the camera ray: only the spheres the tile's cone reaches (a culled sphere is a certain miss for every lane)
                 for (unsigned long long c = cand0; c != 0ull; c &= c - 1ull) {
                     const int i = __builtin_ctzll(c);
-                    const P32G q = load_p32g(recv0 + 4u * (unsigned)i);
+                    const f4 q = x4v0[i];
                     arrive(q);
                     test(q, i);
                 }
             } else if (n > 0) {
-                // (pairs without a check between them, an odd last record after the loop: the loop's bookkeeping is scalar
-                // instructions that cost issue slots like any other)
-                ConstF4 rp = recv0;
-                P32G A = load_p32g(rp), B;
-                int i = 0;
-                for (; i + 1 < n; i += 2) {
-                    arrive(A); B = load_p32g(rp + 4); test(A, i);
-                    arrive(B); A = load_p32g(rp + 8); test(B, i + 1);
+                ConstF4 rp = x4v0;
+                P32W A = load_p32w(rp), B;
+                for (int i = 0;;) {
+                    arrive(A); B = load_p32w(rp + 4); test4(A, i);
+                    if ((i += 4) >= n) break;
+                    arrive(B); A = load_p32w(rp + 8); test4(B, i);
+                    if ((i += 4) >= n) break;
                     rp += 8;
                 }
-                if (i < n) { arrive(A); test(A, i); }
             }
             first = false;
         }
@@ -433,12 +440,12 @@ __device__ V<float> trace_ext_f32(Stack& stack, const unsigned char* block, cons
                         if (j == i) return;                                   // RayTracer.js:76
                         const float c = fmaf(pq.z, Lz, fmaf(pq.y, Ly, pq.x * Lx));
                         if ((ballot(fabsf(c) + 1e-5f >= pq.w) & open_m) == 0ull) return;
-                        const P32G q = load_p32g(recv0 + 4u * (unsigned)j);
+                        const f4 q = x4v0[j];
                         arrive(q);
-                        const float lx = q.g0.x - sox, ly = q.g0.y - soy, lz = q.g0.z - soz;
+                        const float lx = q.x - sox, ly = q.y - soy, lz = q.z - soz;
                         const float b = fmaf(lz, Lz, fmaf(ly, Ly, lx * Lx));
                         const float ll = fmaf(lz, lz, fmaf(ly, ly, lx * lx));
-                        const float disc = fmaf(b, b, q.g1.z - ll);
+                        const float disc = fmaf(b, b, q.w - ll);
                         open_m &= ~ballot(fminf(b, disc) >= 0.0f);            // any hit blocks; distance ignored (F7)
                     };
                     // pre-filter records one ahead, in two buffers that swap roles (rows are padded past n)
