@@ -249,3 +249,42 @@ def test_random_scenes_against_the_specification():
     print(f"{px} pixels: float64 differs on {bad}; float32 beyond 1/255 on {beyond}, worst PSNR {worst:.1f} dB")
     assert bad == 0
     assert beyond <= 5e-4 * px
+
+
+def test_float32_form_with_turned_cameras_bands_and_strips(rdr, scenes):
+    """The float32 bounce loop culls the camera ray's sphere tests per 8 x 8 tile (cone around the tile's centre ray): a wrong
+    cone would make spheres vanish from whole tiles.  Against the float64 kernel (pinned to the specification above) with cameras
+    that are moved, turned and wide, in a band that does not start on a tile row, and in cyclic strips."""
+    import math
+    sc = scenes["example1"]
+    _load(rdr, sc)
+    cams = [dict(origin=(0.0, 0.0, 0.0)),
+            dict(origin=(3.0, 1.5, 4.0)),
+            dict(origin=(-6.0, 2.0, -8.0), right=(math.cos(0.6), 0.0, math.sin(0.6)), up=(0.0, 1.0, 0.0),
+                 forward=(math.sin(0.6), 0.0, -math.cos(0.6))),
+            dict(origin=(0.0, 12.0, -14.0), right=(1.0, 0.0, 0.0), up=(0.0, math.cos(1.0), -math.sin(1.0)),
+                 forward=(0.0, -math.sin(1.0), -math.cos(1.0)), tan_half_fov=math.tan(math.radians(50)))]
+    try:
+        for cam in cams:
+            rdr.set_camera(**cam)
+            for (w, h, y0, rows, depth, spp) in ((333, 201, 0, 201, 4, 1), (256, 160, 13, 90, 3, 3)):
+                f32 = rdr.render(w, h, y0, rows, flags=ptr_amd.MODE_F32_ONLY, max_depth=depth, spp=spp, seed=5)
+                f64 = rdr.render(w, h, y0, rows, flags=X, max_depth=depth, spp=spp, seed=5)
+                d = np.abs(f32.view(np.uint8).astype(np.int16) - f64.view(np.uint8).astype(np.int16)).reshape(-1, 4).max(axis=1)
+                assert int((d > 1).sum()) <= 0.005 * d.size and _psnr(f32, f64) >= 45.0, (cam, w, h, int((d > 1).sum()), _psnr(f32, f64))
+            # cyclic strips of 8 rows (whole tiles: culled) and of 5 rows (not whole tiles: no culling), 3 parts
+            import torch
+            w, h = 200, 120
+            whole = rdr.render(w, h, flags=ptr_amd.MODE_F32_ONLY, max_depth=3).reshape(h, w)
+            for strip in (8, 5):
+                for part_no in range(3):
+                    part = ptr_amd.StripPart(3, part_no, strip)
+                    rows = part.local_rows(h)
+                    buf = torch.zeros((rows, w), dtype=torch.int32, device="cuda")
+                    p = rdr.params(w, h, 0, rows, flags=ptr_amd.MODE_F32_ONLY, max_depth=3)
+                    rdr.render_strips_device(p, part, 0, 1, buf.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+                    torch.cuda.synchronize()
+                    got = buf.cpu().numpy().view(np.uint32)
+                    assert np.array_equal(got, whole[part.global_rows(h)]), (cam, strip, part_no)
+    finally:
+        rdr.set_camera(None)
