@@ -293,7 +293,9 @@ struct RayStack {
 };
 
 // cand0: the spheres a camera ray of this wave's tile can reach at all (bit i; all ones: no such knowledge)
-template <typename Stack>
+// GEN: the scene may have planes (elements n, n + 1, ... after the spheres) and Phong terms (include/ptr.h "planes and Phong");
+// a kernel of its own, so that sphere scenes do not carry its registers.
+template <bool GEN, typename Stack>
 __device__ V<float> trace_ext_f32(Stack& stack, const unsigned char* block, const RenderArgs& a, V<float> o0, V<float> d0, int max_depth,
                                   unsigned long long cand0 = ~0ull)
 {
@@ -307,6 +309,14 @@ __device__ V<float> trace_ext_f32(Stack& stack, const unsigned char* block, cons
     const int n = a.n, nl = hdr->n_lights;
     const float bgx = hdr->bg32[0], bgy = hdr->bg32[1], bgz = hdr->bg32[2];
     constexpr float BIAS = (float)PTR_BIAS;
+    // planes: px py pz refl | nx ny nz transp (camera-relative like the spheres), their materials, the Phong terms (ks per
+    // element, then the exponents)
+    const int np = GEN ? (int)hdr->n_planes : 0;
+    const bool phong = GEN && hdr->has_phong != 0u;
+    const ConstF4 plv0 = (ConstF4)(uintptr_t)(block + (GEN ? hdr->off_pl32 : 0u));
+    const PlaneP32* gpl32 = reinterpret_cast<const PlaneP32*>(block + (GEN ? hdr->off_pl32 : 0u));
+    const SphereM32* gplm32 = reinterpret_cast<const SphereM32*>(block + (GEN ? hdr->off_plm32 : 0u));
+    const float* gph32 = reinterpret_cast<const float*>(block + (GEN ? hdr->off_ph32 : 0u));
 
     // Depth-first expansion with the ray that would be popped next kept in registers: a hit that spawns only a
     // reflection (the usual case) never touches the stack; the order of the rays, and with it the order of the sums, is
@@ -368,15 +378,39 @@ __device__ V<float> trace_ext_f32(Stack& stack, const unsigned char* block, cons
                     rp += 8;
                 }
             }
+            if constexpr (GEN) {
+                // Plane.intersect of the specification: denom = d.n; 0 -> miss; t = ((p - o).n) / denom; t < 0 -> miss
+                for (int q = 0; q < np; q++) {
+                    const f4 p0 = plv0[2 * q], p1 = plv0[2 * q + 1];
+                    arrive(p0); arrive(p1);
+                    const float denom = fmaf(r.d.z, p1.z, fmaf(r.d.y, p1.y, r.d.x * p1.x));
+                    const float num = fmaf(p0.z - r.o.z, p1.z, fmaf(p0.y - r.o.y, p1.y, (p0.x - r.o.x) * p1.x));
+                    const float t = num * rcp(denom);
+                    const bool nearer = (denom != 0.0f) & (t >= 0.0f) & (t < tnear);
+                    tnear = nearer ? t : tnear;
+                    e = nearer ? n + q : e;
+                }
+            }
             first = false;
         }
         if (e < 0) {
             ax = fmaf(r.w.x, bgx, ax); ay = fmaf(r.w.y, bgy, ay); az = fmaf(r.w.z, bgz, az);
             continue;
         }
-        const SphereM32 m = gm32[e];
-        const float4 ce = *reinterpret_cast<const float4*>(&gp32[e].lx);
-        const float refl = gp32[e].refl, transp = gp32[e].transp;
+        const bool on_plane = GEN && e >= n;
+        SphereM32 m;
+        float4 ce;
+        float refl, transp;
+        if (on_plane) {
+            const PlaneP32 pl = gpl32[e - n];
+            m = gplm32[e - n];
+            ce = make_float4(pl.nx, pl.ny, pl.nz, 0.0f);              // (a plane's normal is the unit vector it was given)
+            refl = pl.refl; transp = pl.transp;
+        } else {
+            m = gm32[e];
+            ce = *reinterpret_cast<const float4*>(&gp32[e].lx);
+            refl = gp32[e].refl; transp = gp32[e].transp;
+        }
         ax = fmaf(r.w.x, m.er, ax); ay = fmaf(r.w.y, m.eg, ay); az = fmaf(r.w.z, m.eb, az);
         const V<float> P{fmaf(r.d.x, tnear, r.o.x), fmaf(r.d.y, tnear, r.o.y), fmaf(r.d.z, tnear, r.o.z)};
         V<float> N{P.x - ce.x, P.y - ce.y, P.z - ce.z};
@@ -384,6 +418,7 @@ __device__ V<float> trace_ext_f32(Stack& stack, const unsigned char* block, cons
             const float inv = rsq(fmaf(N.z, N.z, fmaf(N.y, N.y, N.x * N.x)));
             N.x *= inv; N.y *= inv; N.z *= inv;
         }
+        if (on_plane) N = V<float>{ce.x, ce.y, ce.z};
         float dn = fmaf(r.d.z, N.z, fmaf(r.d.y, N.y, r.d.x * N.x));
         const bool inside = dn > 0.0f;
         if (inside) { N.x = -N.x; N.y = -N.y; N.z = -N.z; dn = -dn; }
@@ -421,20 +456,26 @@ __device__ V<float> trace_ext_f32(Stack& stack, const unsigned char* block, cons
             // the reference's direct lighting (RayTracer.js:60-91)
             const float sox = fmaf(N.x, BIAS, P.x), soy = fmaf(N.y, BIAS, P.y), soz = fmaf(N.z, BIAS, P.z);
             float dx = 0.0f, dy = 0.0f, dz = 0.0f;
-            LightQ lq = load_light(lrec0);                                   // LightRec: light kk at a data-independent address
-            for (int kk = 0; kk < nl; kk++) {
-                arrive(lq);
-                const int i = lq.index;
-                const float lgx = lq.g.x, lgy = lq.g.y, lgz = lq.g.z, ler = lq.e.x, leg = lq.e.y, leb = lq.e.z;
-                lq = load_light(lrec0 + 3u * (unsigned)(kk + 1));            // (the table ends with a padding record)
-                const int prow = kk < PTR_MAX_PAIR_LIGHTS ? kk : (n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS);
-                const ConstF4 pairs = pairv0 + (unsigned)prow * (unsigned)pair_stride(n);
+            // Phong term of the specification: ks * max(0, R.L)^exponent per light, R = d - 2 (d.N) N, not tinted by the surface
+            float ks = 0.0f, Rx = 0.0f, Ry = 0.0f, Rz = 0.0f;
+            unsigned pexp = 1u;
+            if constexpr (GEN) if (phong) {
+                ks = gph32[e];
+                pexp = (unsigned)gph32[n + np + e];
+                const float two = 2.0f * dn;
+                Rx = fmaf(-N.x, two, r.d.x); Ry = fmaf(-N.y, two, r.d.y); Rz = fmaf(-N.z, two, r.d.z);
+            }
+            // one light: element i at (lgx, lgy, lgz) with emission (ler, leg, leb); `pairs` = its row of the shadow pre-filter
+            auto light = [&](int i, float lgx, float lgy, float lgz, float ler, float leg, float leb, ConstF4 pairs) {
                 float Lx = lgx - P.x, Ly = lgy - P.y, Lz = lgz - P.z;
-                const float invl = rsq(fmaf(Lz, Lz, fmaf(Ly, Ly, Lx * Lx)));
+                const float len2 = fmaf(Lz, Lz, fmaf(Ly, Ly, Lx * Lx));
+                const float invl = rsq(len2);
                 Lx *= invl; Ly *= invl; Lz *= invl;
                 const float ratio = fmaf(N.z, Lz, fmaf(N.y, Ly, N.x * Lx));
-                // lanes that still need a verdict (max(0, N.L) = 0: the term vanishes either way), as a lane mask
-                unsigned long long open_m = ballot(ratio > 0.0f);
+                float sp = 0.0f;
+                if constexpr (GEN) sp = ks > 0.0f ? fmaf(Rz, Lz, fmaf(Ry, Ly, Rx * Lx)) : 0.0f;
+                // lanes that still need a verdict (max(0, N.L) = 0 and no highlight: the terms vanish either way), as a lane mask
+                unsigned long long open_m = ballot((ratio > 0.0f) | (sp > 0.0f));
                 if (open_m != 0ull && n > 0) {
                     auto occluder = [&](const f4 pq, int j) {
                         if (j == i) return;                                   // RayTracer.js:76
@@ -459,10 +500,50 @@ __device__ V<float> trace_ext_f32(Stack& stack, const unsigned char* block, cons
                         if (++j >= n || open_m == 0ull) break;
                     }
                 }
-                const float lit = lane_of(open_m) ? ratio : 0.0f;
+                if constexpr (GEN) {
+                    // a plane only blocks in front of the light (t^2 < |C - P|^2)
+                    for (int j = 0; j < np && open_m != 0ull; j++) {
+                        if (n + j == i) continue;
+                        const f4 p0 = plv0[2 * j], p1 = plv0[2 * j + 1];
+                        arrive(p0); arrive(p1);
+                        const float denom = fmaf(Lz, p1.z, fmaf(Ly, p1.y, Lx * p1.x));
+                        const float t = fmaf(p0.z - soz, p1.z, fmaf(p0.y - soy, p1.y, (p0.x - sox) * p1.x)) * rcp(denom);
+                        open_m &= ~ballot((denom != 0.0f) & (t >= 0.0f) & (t * t < len2));
+                    }
+                }
+                const bool open = lane_of(open_m);
+                const float lit = (open & (ratio > 0.0f)) ? ratio : 0.0f;
                 dx = fmaf(m.sr * ler, lit, dx);
                 dy = fmaf(m.sg * leg, lit, dy);
                 dz = fmaf(m.sb * leb, lit, dz);
+                if constexpr (GEN) {
+                    if (ballot(open & (sp > 0.0f)) != 0ull) {
+                        float ph = 1.0f, b = sp;
+                        for (unsigned q = pexp; q > 0u; q >>= 1) { ph = (q & 1u) ? ph * b : ph; b = b * b; }
+                        const float kp = (open & (sp > 0.0f)) ? ks * ph : 0.0f;
+                        dx = fmaf(ler, kp, dx); dy = fmaf(leg, kp, dy); dz = fmaf(leb, kp, dz);
+                    }
+                }
+            };
+            LightQ lq = load_light(lrec0);                                   // LightRec: light kk at a data-independent address
+            for (int kk = 0; kk < nl; kk++) {
+                arrive(lq);
+                const int i = lq.index;
+                const float lgx = lq.g.x, lgy = lq.g.y, lgz = lq.g.z, ler = lq.e.x, leg = lq.e.y, leb = lq.e.z;
+                lq = load_light(lrec0 + 3u * (unsigned)(kk + 1));            // (the table ends with a padding record)
+                const int prow = kk < PTR_MAX_PAIR_LIGHTS ? kk : (n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS);
+                light(i, lgx, lgy, lgz, ler, leg, leb, pairv0 + (unsigned)prow * (unsigned)pair_stride(n));
+            }
+            if constexpr (GEN) {
+                // the emissive planes are lights too (at their point p), after the spheres; no pre-filter row for them
+                const ConstF4 norow = pairv0 + (unsigned)(n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS) * (unsigned)pair_stride(n);
+                for (int q = 0; q < np; q++) {
+                    const f4 p0 = plv0[2 * q];
+                    const f4 e0 = *reinterpret_cast<ConstF4>((uintptr_t)(gplm32 + q) + 16);    // er eg eb emax
+                    arrive(p0); arrive(e0);
+                    if (!(e0.x > 0.0f || e0.y > 0.0f || e0.z > 0.0f)) continue;
+                    light(n + q, p0.x, p0.y, p0.z, e0.x, e0.y, e0.z, norow);
+                }
             }
             ax = fmaf(r.w.x, dx, ax); ay = fmaf(r.w.y, dy, ay); az = fmaf(r.w.z, dz, az);
         }
@@ -565,8 +646,8 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_ext_kernel(RenderArgs a)
     }
 }
 
-// The float32 form on a scene of spheres without Phong terms, as a kernel of its own: the general float32 path (planes,
-// Phong terms; trace_ext<float>) in the same kernel costs it 19 VGPRs it never uses.
+// The float32 form, one instance for scenes of spheres alone and one for scenes with planes or Phong terms (which costs
+// registers the first never uses; trace_ext<float>, the same arithmetic lane by lane, is what both are checked against).
 #ifndef PTR_EXT_WAVES
 #define PTR_EXT_WAVES 7
 #endif
@@ -575,7 +656,8 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_ext_kernel(RenderArgs a)
 #else
 #define PTR_EXT_OCC
 #endif
-__global__ void __launch_bounds__(64) PTR_EXT_OCC render_ext_f32_kernel(RenderArgs a)
+template <bool GEN>
+__device__ __forceinline__ void render_ext_f32_body(const RenderArgs& a)
 {
     const int lane = threadIdx.x;
     const int x = blockIdx.x * 8 + (lane & 7), row = blockIdx.y * PTR_TILE_H + (lane >> 3), frame = blockIdx.z;
@@ -610,11 +692,22 @@ __global__ void __launch_bounds__(64) PTR_EXT_OCC render_ext_f32_kernel(RenderAr
     V<float> sum{0, 0, 0};
     for (int s = 0; s < a.spp; s++) {
         const V<float> d = ext_camera_dir<float>(a, x, y, s);
-        const V<float> c = trace_ext_f32(st, block, a, V<float>{0, 0, 0}, d, a.max_depth, cand);
+        const V<float> c = trace_ext_f32<GEN>(st, block, a, V<float>{0, 0, 0}, d, a.max_depth, cand);
         sum.x += c.x; sum.y += c.y; sum.z += c.z;
     }
     ext_store<float>(a, frame, x, row, sum);
 }
+
+__global__ void __launch_bounds__(64) PTR_EXT_OCC render_ext_f32_kernel(RenderArgs a) { render_ext_f32_body<false>(a); }
+#ifndef PTR_EXT_GEN_WAVES
+#define PTR_EXT_GEN_WAVES 7
+#endif
+#if PTR_EXT_GEN_WAVES > 0
+#define PTR_EXT_GEN_OCC __attribute__((amdgpu_waves_per_eu(PTR_EXT_GEN_WAVES, PTR_EXT_GEN_WAVES)))
+#else
+#define PTR_EXT_GEN_OCC
+#endif
+__global__ void __launch_bounds__(64) PTR_EXT_GEN_OCC render_ext_f32_gen_kernel(RenderArgs a) { render_ext_f32_body<true>(a); }
 
 hipError_t launch_render_ext(const RenderArgs& a, int n_frames, bool f64, bool stats, bool spheres_only, hipStream_t s)
 {
@@ -628,7 +721,7 @@ hipError_t launch_render_ext(const RenderArgs& a, int n_frames, bool f64, bool s
         // expands a tree of rays), and a one-wave workgroup starts wherever a slot is free
         const dim3 grid1((a.width + 7) / 8, grid.y, n_frames);
         if (spheres_only) hipLaunchKernelGGL(render_ext_f32_kernel, grid1, dim3(64), 0, s, a);
-        else hipLaunchKernelGGL((render_ext_kernel<float, false>), grid1, dim3(64), 0, s, a);
+        else hipLaunchKernelGGL(render_ext_f32_gen_kernel, grid1, dim3(64), 0, s, a);
     }
     return hipGetLastError();
 }
