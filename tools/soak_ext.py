@@ -1,6 +1,6 @@
 """Soak test (GPU) of the extension modes: the float64 kernel (the default mode) against the CPU specification
 (oracle/ptr_oracle.c orc_render_ext) on random scenes with reflective and transparent spheres, random depth, samples and
-frame size - every byte must be equal - and, beside it, what the float32 form leaves (pixels beyond 1/255, PSNR).
+frame size, a third of them with planes and Phong terms - every byte must be equal - and, beside it, what the float32 form leaves (pixels beyond 1/255, PSNR).
     python tools/soak_ext.py [scenes] [seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,9 +40,32 @@ def soak(n_scenes, seed, verbose=True):
         if depth == 0 and spp == 1:
             depth = 1
         soa = np.ascontiguousarray(soa)
-        r.set_scene(soa); r.set_background(bg)
+        # every third scene: 1-3 planes (a floor, walls, a tilted emissive panel) and / or Phong terms
+        planes = phong = None
+        if k % 3 == 1:
+            n_pl = int(rng.integers(0, 4))
+            if n_pl:
+                planes = np.zeros((14, n_pl))
+                for q in range(n_pl):
+                    nrm = rng.normal(size=3) if q else np.array([0.0, 1.0, 0.0])
+                    nrm /= np.sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2])
+                    pt = np.array([0.0, -4.0 - rng.uniform(0, 3), -20.0]) if q == 0 else rng.uniform(-40, 40, 3) + np.array([0, 0, -30.0])
+                    planes[0:3, q] = pt; planes[3:6, q] = nrm
+                    planes[6:9, q] = rng.uniform(0.1, 0.9, 3)
+                    planes[9, q] = float(rng.random() < 0.3); planes[10, q] = 0.0
+                    if q == 2:
+                        planes[11:14, q] = rng.uniform(0.1, 0.5, 3)
+            if n_pl == 0 or rng.random() < 0.6:
+                ne = n + n_pl
+                phong = np.zeros((2, ne)); phong[1] = 1.0
+                sel = rng.random(ne) < 0.5
+                phong[0, sel] = rng.uniform(0.1, 0.8, int(sel.sum())); phong[1, sel] = rng.integers(1, 200, int(sel.sum()))
+        r.set_scene(soa); r.set_background(bg); r.set_extension(planes, phong)
         got = r.render(w, h, flags=0, max_depth=depth, spp=spp, seed=seed)
-        want = orc.render_ext(soa, bg, w, h, max_depth=depth, spp=spp, seed=seed)
+        if planes is None and phong is None:
+            want = orc.render_ext(soa, bg, w, h, max_depth=depth, spp=spp, seed=seed)
+        else:
+            want = orc.render_ext2(soa, bg, w, h, planes=planes, phong=phong, max_depth=depth, spp=spp, seed=seed)
         bad = int((got != want).sum())
         f32 = r.render(w, h, flags=ptr_amd.MODE_F32_ONLY, max_depth=depth, spp=spp, seed=seed)
         a = f32.view(np.uint8).reshape(-1, 4)[:, :3].astype(np.int32); b = want.view(np.uint8).reshape(-1, 4)[:, :3].astype(np.int32)
