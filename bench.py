@@ -40,11 +40,11 @@ STRIP = 8
 PEAK_FP32_VALU_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
 PEAK_HBM_GBPS = 8000.0
 # HBM traffic of the float32 kernel per pixel, from the PMC passes of this very command kept under profiles/
-# (r02_summary.md: WRITE_SIZE 2 581 070 KB and FETCH_SIZE 9 703.6 KB per launch of 256 x 1920 x 1080 pixels; gfx950
+# (r02_summary.md: WRITE_SIZE 2 581 240 KB and FETCH_SIZE 9 680.6 KB per launch of 256 x 1920 x 1080 pixels; gfx950
 # correction of the guide applied: FETCH_SIZE counts 64 B per 128-B request -> x 2).  Counters cannot be read from
 # inside this process, so the per-launch figure reported below is this profiled rate times the launch's pixels
 # (reported as "traffic", with "traffic_source" saying so).
-PROFILED_HBM_BYTES_PER_PIXEL = (2581070.0 * 1024 + 2 * 9703.55 * 1024) / (256 * 1920 * 1080)
+PROFILED_HBM_BYTES_PER_PIXEL = (2581240.0 * 1024 + 2 * 9680.56 * 1024) / (256 * 1920 * 1080)
 
 
 def example1_soa():
