@@ -9,7 +9,8 @@
 //   Driver.age (:936-942), getCacheUsage, the four frame getters (:960-1046)
 // The reference does all of this sequentially; the order only matters in three places, and each has a parallel form
 // that gives the same state:
-//   * the candidate list is a stable compaction of the pixels in walk order (hipCUB select over a walk-order iterator);
+//   * the candidate list is a stable compaction of the pixels in walk order: count per 2 048 walk steps, one workgroup's
+//     scan of the counts, write (the library's select did the same with two small fills and a threshold kernel before it);
 //   * the picks are `Math.round` of a running float64 sum, which is piecewise linear in integers (RcPickSegments): the
 //     host finds the few pieces, every lane evaluates its own step;
 //   * the diffused amount depends on the priority of ONE pixel, the last of the walk, which only two picks can change
@@ -19,8 +20,6 @@
 //     page is never looked at twice in one launch).
 // All of it is integer / byte / float64 work on a few words per request; nothing here is near a roofline of its own.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
-
 #include <climits>
 
 #include "ptr_device.h"
@@ -35,48 +34,115 @@ __device__ __forceinline__ int rc_last_pixel(const RcLoopArgs& a)      // where 
     return a.height * (a.width + 2) + ((a.height & 1) ? 1 : a.width);
 }
 
-// Driver.js:690-706.  `samples === null` only for the first level; a budget that is never exceeded leaves threshold null.
-__global__ void __launch_bounds__(256) rc_threshold_kernel(RcLoopArgs a)
+constexpr int RC_CHUNK = 2048;                                  // walk steps per workgroup of the compaction (256 lanes x 8)
+
+// exclusive prefix sum of one int per lane over a 256-lane workgroup (4 waves); *total = the workgroup's sum
+__device__ __forceinline__ int rc_block_exclusive(int v, int* wave_sums /* 4, shared */, int* total)
 {
-    __shared__ double level[256];                               // URGENT + INTERPOLATED + SAMPLED per priority level
-    level[threadIdx.x] = (double)a.hist[256 + threadIdx.x] + (double)a.hist[threadIdx.x] + (double)a.hist[512 + threadIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(inc, off, 64); if (lane >= off) inc += u; }
+    if (lane == 63) wave_sums[wave] = inc;
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    double samples = 0;
-    bool first = true;
-    int threshold = -1;
-    for (int i = a.priority_max; i >= 0; i--) {
-        double test = level[i];
-        if (first) { samples = test; test = 0; first = false; }
-        if (samples + test > a.max_samples) { threshold = i; samples += test; break; }
-        samples += test;
-    }
-    RcLoopWords& w = *a.words;
-    w.samples = samples;
-    w.threshold = threshold;
-    w.thr_value = threshold < 0 ? 0 : threshold;
-    w.candidates = 0;
-    w.k_a = INT_MAX; w.k_b = INT_MAX;
-    w.half[0] = w.half[1] = w.half[2] = -1;
-    w.n_need = 0;
-    w.used = 0;
+    int base = 0;
+    for (int w = 0; w < wave; w++) base += wave_sums[w];
+    *total = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
+    __syncthreads();                                            // (wave_sums may be written again by the caller's next scan)
+    return base + inc - v;
 }
 
 // k-th pixel of the walk (Driver.js:713-760): rows 1..height, even rows left to right, odd rows right to left
-struct WalkPixel {
-    int width;
-    __host__ __device__ int operator()(int k) const
-    {
-        const int y = k / width + 1, j = k - (y - 1) * width;
-        return y * (width + 2) + ((y & 1) ? width - j : 1 + j);
-    }
-};
+__device__ __forceinline__ int rc_walk_pixel(int k, int width)
+{
+    const int y = k / width + 1, j = k - (y - 1) * width;
+    return y * (width + 2) + ((y & 1) ? width - j : 1 + j);
+}
 
-struct AtThreshold {
-    const int32_t* priority;
-    const RcLoopWords* words;
-    __device__ bool operator()(int p) const { return priority[p] >= words->thr_value; }
-};
+// Driver.js:690-706 by a whole workgroup: lane i holds priority level i (URGENT + INTERPOLATED + SAMPLED).  The reference
+// walks the levels downwards and stops at the first whose running sum exceeds the budget (`samples === null` only makes the
+// first level its own start); the sums are of integers, exact in float64 in any order, so: C_i = sum of the levels >= i,
+// threshold = the largest i with C_i > budget (null if none), samples = C_threshold (C_0 if none).
+__device__ __forceinline__ void rc_find_threshold(const RcLoopArgs& a, double* lev /* 256, shared */, int* s_thr /* shared */,
+                                                  int& threshold, double& samples)
+{
+    const int i = threadIdx.x;
+    lev[i] = i <= a.priority_max ? (double)a.hist[256 + i] + (double)a.hist[i] + (double)a.hist[512 + i] : 0.0;
+    if (i == 0) *s_thr = -1;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {                   // suffix sums
+        const double u = i + off < 256 ? lev[i + off] : 0.0;
+        __syncthreads();
+        lev[i] += u;
+        __syncthreads();
+    }
+    if (i <= a.priority_max && lev[i] > a.max_samples) atomicMax(s_thr, i);
+    __syncthreads();
+    threshold = *s_thr;
+    samples = lev[threshold < 0 ? 0 : threshold];
+}
+
+// candidates, pass 1: every workgroup finds the threshold for itself (the first one records it) and counts its 2 048 walk steps
+__global__ void __launch_bounds__(256) rc_cand_count_kernel(RcLoopArgs a, int32_t* block_count)
+{
+    __shared__ double lev[256];
+    __shared__ int s_thr, wave_sums[4];
+    int threshold; double samples;
+    rc_find_threshold(a, lev, &s_thr, threshold, samples);
+    const int thr_value = threshold < 0 ? 0 : threshold;        // what `>= threshold` sees: null compares as 0
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        RcLoopWords& w = *a.words;
+        w.samples = samples;
+        w.threshold = threshold;
+        w.thr_value = thr_value;
+        w.candidates = 0;
+        w.k_a = INT_MAX; w.k_b = INT_MAX;
+        w.half[0] = w.half[1] = w.half[2] = -1;
+        w.n_need = 0;
+        w.used = 0;
+    }
+    const int n = a.width * a.height, k0 = (blockIdx.x * 256 + threadIdx.x) * 8;
+    int c = 0;
+    for (int j = 0; j < 8; j++)
+        if (k0 + j < n) c += a.pixel_priority[rc_walk_pixel(k0 + j, a.width)] >= thr_value ? 1 : 0;
+    int total;
+    (void)rc_block_exclusive(c, wave_sums, &total);
+    if (threadIdx.x == 0) block_count[blockIdx.x] = total;
+}
+
+// pass 2 (one workgroup): counts -> offsets, in place; the total is the number of candidates
+__global__ void __launch_bounds__(256) rc_cand_offsets_kernel(int32_t* block_count, int n_blocks, RcLoopWords* words)
+{
+    __shared__ int wave_sums[4];
+    int carry = 0;
+    for (int b0 = 0; b0 < n_blocks; b0 += 256) {
+        const int b = b0 + threadIdx.x;
+        const int v = b < n_blocks ? block_count[b] : 0;
+        int total;
+        const int ex = rc_block_exclusive(v, wave_sums, &total);
+        if (b < n_blocks) block_count[b] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) words->candidates = carry;
+}
+
+// pass 3: the candidates, in walk order
+__global__ void __launch_bounds__(256) rc_cand_write_kernel(RcLoopArgs a, const int32_t* block_off)
+{
+    __shared__ int wave_sums[4];
+    const int thr_value = a.words->thr_value;
+    const int n = a.width * a.height, k0 = (blockIdx.x * 256 + threadIdx.x) * 8;
+    int px[8], c = 0;
+    unsigned flags = 0u;
+    for (int j = 0; j < 8; j++) {
+        px[j] = k0 + j < n ? rc_walk_pixel(k0 + j, a.width) : 0;
+        if (k0 + j < n && a.pixel_priority[px[j]] >= thr_value) { flags |= 1u << j; c++; }
+    }
+    int total;
+    int at = block_off[blockIdx.x] + rc_block_exclusive(c, wave_sums, &total);
+    for (int j = 0; j < 8; j++)
+        if (flags >> j & 1u) a.cand[at++] = px[j];
+}
 
 // which candidate step k requests: Math.round of the running sum (see RcPickSegments)
 __global__ void __launch_bounds__(256) rc_pick_index_kernel(int32_t* pick_index, int n_picks, RcPickSegments g)
@@ -89,22 +155,40 @@ __global__ void __launch_bounds__(256) rc_pick_index_kernel(int32_t* pick_index,
     pick_index[k] = (int32_t)js_round(__builtin_scalbn((double)S, g.e[seg]));
 }
 
-__global__ void __launch_bounds__(256) rc_pick_kernel(RcLoopArgs a)
+__global__ void __launch_bounds__(256) rc_pick_kernel(RcLoopArgs a, int32_t* block_need)
 {
+    __shared__ int wave_sums[4];
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= a.n_picks) return;
-    const int st = a.width + 2, p = a.cand[a.pick_index[k]];
-    a.pixel_sample[p] = 1;                                      // addRequest (:312)
-    a.need[k] = a.pixel_element[p] < 0 ? 1 : 0;
-    const int last = rc_last_pixel(a), dx_last = (a.height & 1) ? -1 : 1;
-    if (p == last - st) a.words->k_a = k;                       // its lower neighbour is the walk's last pixel
-    if (p == last - dx_last) a.words->k_b = k;                  // its neighbour in walk direction is
+    int need = 0;
+    if (k < a.n_picks) {
+        const int st = a.width + 2, p = a.cand[a.pick_index[k]];
+        a.pixel_sample[p] = 1;                                  // addRequest (:312)
+        need = a.pixel_element[p] < 0 ? 1 : 0;
+        a.need[k] = need;
+        const int last = rc_last_pixel(a), dx_last = (a.height & 1) ? -1 : 1;
+        if (p == last - st) a.words->k_a = k;                   // its lower neighbour is the walk's last pixel
+        if (p == last - dx_last) a.words->k_b = k;              // its neighbour in walk direction is
+    }
+    int total;
+    (void)rc_block_exclusive(need, wave_sums, &total);          // this workgroup's requests without an item
+    if (threadIdx.x == 0) block_need[blockIdx.x] = total;
 }
 
-// the three diffused amounts and the number of requests without an item; runs after the sum of the need flags
-__global__ void rc_amounts_kernel(RcLoopArgs a)
+// one workgroup: the workgroups' need counts -> offsets (in place), their total = the requests without an item; then the
+// three diffused amounts
+__global__ void __launch_bounds__(256) rc_amounts_kernel(RcLoopArgs a, int32_t* block_need, int n_blocks)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    __shared__ int wave_sums[4];
+    int carry = 0;
+    for (int b0 = 0; b0 < n_blocks; b0 += 256) {
+        const int b = b0 + threadIdx.x;
+        const int v = b < n_blocks ? block_need[b] : 0;
+        int total;
+        const int ex = rc_block_exclusive(v, wave_sums, &total);
+        if (b < n_blocks) block_need[b] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x != 0) return;
     RcLoopWords& w = *a.words;
     int pr = a.pixel_priority[rc_last_pixel(a)];
     const int thr = w.thr_value;
@@ -114,13 +198,19 @@ __global__ void rc_amounts_kernel(RcLoopArgs a)
     if (w.k_b != INT_MAX && h1 >= 0) pr += h1;
     const int h2 = (pr - thr) >> 1;
     w.half[0] = h0; w.half[1] = h1; w.half[2] = h2;
-    w.n_need = a.n_picks > 0 ? a.rank[a.n_picks - 1] + a.need[a.n_picks - 1] : 0;
+    w.n_need = carry;
 }
 
-__global__ void __launch_bounds__(256) rc_diffuse_kernel(RcLoopArgs a)
+// ... and, with the same lane-to-request mapping as rc_pick_kernel, every request's number among those without an item
+__global__ void __launch_bounds__(256) rc_diffuse_kernel(RcLoopArgs a, const int32_t* block_need_off)
 {
+    __shared__ int wave_sums[4];
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= a.n_picks) return;
+    const bool live = k < a.n_picks;
+    int total;
+    const int ex = rc_block_exclusive(live ? a.need[k] : 0, wave_sums, &total);
+    if (!live) return;
+    a.rank[k] = block_need_off[blockIdx.x] + ex;
     const RcLoopWords& w = *a.words;
     const int st = a.width + 2, p = a.cand[a.pick_index[k]];
     const int half = w.half[k > w.k_b ? 2 : k > w.k_a ? 1 : 0];
@@ -240,41 +330,38 @@ __global__ void __launch_bounds__(256) rc_frames_kernel(RcLoopArgs a)
     if (a.frames[3]) a.frames[3][at] = a.pixel_sample[p] ? 0xffffffffu : 0xff000000u;
 }
 
-using WalkIterator = hipcub::TransformInputIterator<int, WalkPixel, hipcub::CountingInputIterator<int>>;
-
 inline dim3 blocks_for(int n) { return dim3((unsigned)((n + 255) / 256)); }
 
 }  // namespace
 
+// scratch of the candidate compaction (a count per 2 048 walk steps) and of the requests' ranks (a count per 256 requests)
 size_t rc_loop_temp_bytes(int width, int height)
 {
-    const int px = width * height;
-    size_t a = 0, b = 0;
-    WalkIterator walk(hipcub::CountingInputIterator<int>(0), WalkPixel{width});
-    if (hipcub::DeviceSelect::If(nullptr, a, walk, (int32_t*)nullptr, (int32_t*)nullptr, px, AtThreshold{nullptr, nullptr}) != hipSuccess)
-        return 0;
-    if (hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const int32_t*)nullptr, (int32_t*)nullptr, px) != hipSuccess) return 0;
-    return a > b ? a : b;
+    const size_t px = (size_t)width * (size_t)height;
+    return ((px + RC_CHUNK - 1) / RC_CHUNK + (px + 255) / 256 + 64) * sizeof(int32_t);
 }
 
 hipError_t launch_rc_candidates(const RcLoopArgs& a, void* temp, size_t temp_bytes, hipStream_t s)
 {
-    hipLaunchKernelGGL(rc_threshold_kernel, dim3(1), dim3(256), 0, s, a);
-    WalkIterator walk(hipcub::CountingInputIterator<int>(0), WalkPixel{a.width});
-    return hipcub::DeviceSelect::If(temp, temp_bytes, walk, a.cand, &a.words->candidates, a.width * a.height,
-                                    AtThreshold{a.pixel_priority, a.words}, s);
+    const int n = a.width * a.height, blocks = (n + RC_CHUNK - 1) / RC_CHUNK;
+    if (temp_bytes < rc_loop_temp_bytes(a.width, a.height)) return hipErrorInvalidValue;
+    int32_t* counts = static_cast<int32_t*>(temp);
+    hipLaunchKernelGGL(rc_cand_count_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, counts);
+    hipLaunchKernelGGL(rc_cand_offsets_kernel, dim3(1), dim3(256), 0, s, counts, blocks, a.words);
+    hipLaunchKernelGGL(rc_cand_write_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, (const int32_t*)counts);
+    return hipGetLastError();
 }
 
 hipError_t launch_rc_requests(const RcLoopArgs& a, const RcPickSegments& picks, void* temp, size_t temp_bytes, hipStream_t s)
 {
     if (a.n_picks <= 0) return hipSuccess;
+    if (temp_bytes < rc_loop_temp_bytes(a.width, a.height)) return hipErrorInvalidValue;
     const dim3 grid = blocks_for(a.n_picks);
+    int32_t* block_need = static_cast<int32_t*>(temp) + (a.width * a.height + RC_CHUNK - 1) / RC_CHUNK;
     if (picks.n > 0) hipLaunchKernelGGL(rc_pick_index_kernel, grid, dim3(256), 0, s, a.pick_index, a.n_picks, picks);   // else: the host sent them
-    hipLaunchKernelGGL(rc_pick_kernel, grid, dim3(256), 0, s, a);
-    hipError_t e = hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, a.need, a.rank, a.n_picks, s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(rc_amounts_kernel, dim3(1), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(rc_diffuse_kernel, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(rc_pick_kernel, grid, dim3(256), 0, s, a, block_need);
+    hipLaunchKernelGGL(rc_amounts_kernel, dim3(1), dim3(256), 0, s, a, block_need, (int)grid.x);
+    hipLaunchKernelGGL(rc_diffuse_kernel, grid, dim3(256), 0, s, a, (const int32_t*)block_need);
     for (long long lo = 0; lo < a.n_picks; lo += a.pages) {     // one launch unless a frame requests more items than there are pages
         RcLoopArgs b = a;
         b.rank_lo = (int)lo;
