@@ -1060,7 +1060,8 @@ int rc_check(ptr_ctx* c, const ptr_rc_camera* cam, int n_items, const void* hit,
 
 // enqueue the pass on stream s; all data pointers are device memory.  Caller holds c->mu.
 int rc_enqueue(ptr_ctx* c, const ptr_rc_camera* cam, int n_items, const double* d_hit, double* d_age, double age_factor,
-               double depth_threshold, int32_t* d_item_pixel, int32_t* d_pel, double* d_pdep, hipStream_t s, int item_base = 0)
+               double depth_threshold, int32_t* d_item_pixel, int32_t* d_pel, double* d_pdep, hipStream_t s, int item_base = 0,
+               uint8_t* d_pixel_sample = nullptr)      // (the frame loop's sample flags: cleared with the grid's interior)
 {
     const size_t n = (size_t)(n_items > 0 ? n_items : 1);
     PTR_TRY(grow(c, c->rc_depth, n * sizeof(double)));
@@ -1075,6 +1076,7 @@ int rc_enqueue(ptr_ctx* c, const ptr_rc_camera* cam, int n_items, const double* 
     a.width = cam->width; a.height = cam->height; a.n_items = n_items; a.item_base = item_base;
     a.age_factor = age_factor; a.depth_threshold = depth_threshold;
     a.hit_xyz = d_hit; a.age = d_age; a.item_pixel = d_item_pixel; a.pixel_element = d_pel; a.pixel_depth = d_pdep;
+    a.pixel_sample = d_pixel_sample;
     a.item_depth = static_cast<double*>(c->rc_depth.ptr);
     uint32_t* k = static_cast<uint32_t*>(c->rc_keys.ptr);
     a.sort_key = k; a.sort_val = k + n; a.sorted_key = k + 2 * n; a.sorted_val = k + 3 * n;
@@ -1453,8 +1455,8 @@ int ptr_rc_next_frame(ptr_ctx* c, const ptr_rc_view* view, const ptr_rc_loop_par
     cam.width = w; cam.height = h;
     PTR_TRY(rc_enqueue(c, &cam, r.n_items, static_cast<const double*>(r.item_hit.ptr), static_cast<double*>(r.item_age.ptr),
                        par->age_factor, par->depth_threshold, static_cast<int32_t*>(r.item_pixel.ptr),
-                       static_cast<int32_t*>(r.pixel_element.ptr), static_cast<double*>(r.pixel_depth.ptr), s));
-    HIP_TRY(c, hipMemset2DAsync(static_cast<uint8_t*>(r.pixel_sample.ptr) + st + 1, (size_t)st, 0, (size_t)w, (size_t)h, s));
+                       static_cast<int32_t*>(r.pixel_element.ptr), static_cast<double*>(r.pixel_depth.ptr), s, 0,
+                       static_cast<uint8_t*>(r.pixel_sample.ptr)));
 
     // depthCulling + fillGaps
     ptr_rc_shade_params sp = {w, h, par->age_factor, par->interpolation_zero, par->interpolation_random, par->priority_max};

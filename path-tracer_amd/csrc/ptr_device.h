@@ -207,6 +207,7 @@ struct RcArgs {
     int32_t* item_pixel;                     // out: pixel (y * (width + 2) + x) the item was attached to, or -1
     int32_t* pixel_element;                  // out, (width + 2) * (height + 2), interior only
     double* pixel_depth;                     // out, same grid
+    uint8_t* pixel_sample;                   // nullable: the frame loop's per-pixel sample flags, cleared with the interior
     // scratch owned by the context
     double* item_depth;
     uint32_t *sort_key, *sort_val, *sorted_key, *sorted_val;

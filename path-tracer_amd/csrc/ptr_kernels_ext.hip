@@ -300,7 +300,6 @@ __device__ V<float> trace_ext_f32(Stack& stack, const unsigned char* block, cons
                                   unsigned long long cand0 = ~0ull)
 {
     const ConstHeader hdr = (ConstHeader)(uintptr_t)block;
-    const ConstF4 recv0 = (ConstF4)(uintptr_t)(block + a.off_p32);      // the same table through loads that stay where they are written
     const ConstF4 x4v0 = (ConstF4)(uintptr_t)(block + a.off_x4);        // lx ly lz r2 per sphere, padded with never-hit records
     const ConstF4 pairv0 = (ConstF4)(uintptr_t)(block + a.off_pairs);
     const ConstF4 lrec0 = (ConstF4)(uintptr_t)(block + a.off_lrec);

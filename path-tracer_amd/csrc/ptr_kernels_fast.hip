@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
     // then visits the set bits only.
     unsigned cand = (1u << n) - 1u;                    // n <= PTR_FAST_MAX_SPHERES
     if (a.cull_on) {
-        const int x0 = blockIdx.x * (PTR_FAST_BLOCK / 64 * 8 * PPL) + wave * (8 * PPL), row0 = blockIdx.y * PTR_TILE_H;
+        const int x0 = blockIdx.x * (PTR_FAST_BLOCK / 64 * 8 * PPL) + wave * (8 * PPL);
         const float xc = fmaf((float)(x0 + 4 * PPL), a.camf.sx, a.camf.ox);
         const float yc = fmaf((float)(gy0 + PTR_TILE_H / 2), a.camf.sy, a.camf.oy);     // (cull_on implies consecutive rows)
         F3 dc;

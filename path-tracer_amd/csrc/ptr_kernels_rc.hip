@@ -31,6 +31,7 @@ __global__ void __launch_bounds__(256) rc_clear_kernel(RcArgs a)
     const size_t p = (size_t)y * (a.width + 2) + x;
     a.pixel_element[p] = -1;
     a.pixel_depth[p] = a.depth_threshold;
+    if (a.pixel_sample) a.pixel_sample[p] = 0;
 }
 
 // THREE.Vector3.applyMatrix4 (three.js r139): column-major elements, perspective divide
@@ -270,10 +271,16 @@ __global__ void __launch_bounds__(256) rc_fill_kernel(RcShadeArgs a)
 
 hipError_t launch_rc_shade(const RcShadeArgs& a, hipStream_t s)
 {
-    hipError_t e = hipMemsetAsync(a.hist, 0, 3 * 256 * sizeof(uint32_t), s);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(a.totals, 0, 3 * sizeof(long long), s);
-    if (e != hipSuccess) return e;
+    hipError_t e;
+    if (reinterpret_cast<unsigned char*>(a.totals) == reinterpret_cast<unsigned char*>(a.hist) + 3 * 256 * sizeof(uint32_t)) {
+        e = hipMemsetAsync(a.hist, 0, 3 * 256 * sizeof(uint32_t) + 3 * sizeof(long long), s);      // (one small fill, not two)
+        if (e != hipSuccess) return e;
+    } else {
+        e = hipMemsetAsync(a.hist, 0, 3 * 256 * sizeof(uint32_t), s);
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(a.totals, 0, 3 * sizeof(long long), s);
+        if (e != hipSuccess) return e;
+    }
     dim3 grid((a.width + 255) / 256, a.height);
     hipLaunchKernelGGL(rc_cull_kernel, grid, dim3(256), 0, s, a);
     dim3 fill_grid(grid.x, a.height < 128 ? a.height : 128);
