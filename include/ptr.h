@@ -39,12 +39,20 @@ extern "C" {
  * first row is dropped and its last stored row stays 0x00000000.  The drop-in
  * RayTracer.render() sets it; renderFrame()/benchmarks do not. */
 #define PTR_QUIRK_ROW_SHIFT   0x0001u
-/* Precision mode (at most one).  Default (neither bit): HYBRID — every pixel is traced in
+/* Precision mode (at most one).  Default (no mode bit): HYBRID — every pixel is traced in
  * float32 with conservative uncertainty tests; pixels whose hit/miss, ordering, shadow or
  * 8-bit rounding decision is not certain are queued and re-traced by the float64 kernel,
  * which follows the reference operation for operation.  Output target: identical bytes.   */
 #define PTR_MODE_EXACT_F64    0x0002u  /* whole band in float64, op-for-op the reference      */
 #define PTR_MODE_F32_ONLY     0x0004u  /* float32 only, no re-trace (tolerance mode)          */
+/* HYBRID within north_star's tolerance instead of identical bytes: every pixel is traced in float32 and only the
+ * DISCONTINUOUS doubts (hit/miss, nearest-vs-second, far clip, shadow any-hit: a flip there moves a pixel by far more
+ * than 1/255) are re-traced in float64.  A pixel whose decisions are all certain keeps its float32 colour when the summed
+ * error bounds of its N.L terms keep that colour within one 8-bit unit of the float64 one (re-traced otherwise), so every
+ * channel of every pixel is within 1 of the reference's byte; what the default pays for equal bytes - the 8-bit rounding
+ * doubt, its error sums and the shading-only re-do - is not paid.  Reference semantics only (max_depth 0, spp 1, no planes,
+ * no Phong terms; with more than 12 spheres the mode is accepted and renders as the default does).                          */
+#define PTR_MODE_TOLERANT     0x0020u
 /* Accumulate work counters (ptr_get_stats) during this call; slower, not for timing.        */
 #define PTR_FLAG_STATS        0x0008u
 /* Bracket this call's kernels with HIP events on the launch stream (ptr_get_kernel_ms).        */

@@ -347,6 +347,18 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
         h->bg64[k] = bg[k];
         h->bg32[k] = (float)bg[k];
     }
+    {
+        // PTR_MODE_TOLERANT: |float32 colour - float64 colour| <= scmax * sum_k emax_k * (|error of N.L_k| + 15 eps) (+ the
+        // roundings of the sums, far below); N.L_k is off by at most eN + eL_k, which the kernel sums over the lights (S).
+        // 255 * scmax * (sum_k emax_k) * (S + 15 eps) <= 0.9 keeps the two colours within one 8-bit unit BEFORE rounding, so the
+        // rounded bytes differ by at most 1.  No lights: nothing is shaded from N.L, any S will do.
+        double scm = 0.0, esum = 0.0;
+        for (int i = 0; i < n; i++) scm = std::fmax(scm, (double)m32[i].scmax);
+        for (int k = 0; k < nl; k++) esum += (double)m32[lights[k]].emax;
+        const double den = 255.0 * scm * esum;
+        const double thr = den > 0 ? 0.9 / den - 16.0 * EPS32 : 3.0e38;
+        h->tol_thr = std::isfinite(thr) ? (float)std::fmin(thr, 3.0e38) : -1.0f;     // (<= 0: every hit pixel is re-traced)
+    }
     h->n = n;
     h->n_lights = nl;
     h->bg_packed = pack_js(bg[0], bg[1], bg[2]);
@@ -460,8 +472,8 @@ int check_params(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frames)
                                             "(max_depth 0, spp 1, no planes, no Phong terms); got max_depth=%d spp=%d planes=%d",
                         p->max_depth, p->spp, c->n_planes);
     }
-    if ((p->flags & PTR_MODE_EXACT_F64) && (p->flags & PTR_MODE_F32_ONLY))
-        return fail(c, PTR_ERR_INVALID, "PTR_MODE_EXACT_F64 and PTR_MODE_F32_ONLY are exclusive");
+    if (((p->flags & PTR_MODE_EXACT_F64) != 0) + ((p->flags & PTR_MODE_F32_ONLY) != 0) + ((p->flags & PTR_MODE_TOLERANT) != 0) > 1)
+        return fail(c, PTR_ERR_INVALID, "PTR_MODE_EXACT_F64, PTR_MODE_F32_ONLY and PTR_MODE_TOLERANT are exclusive");
     return PTR_OK;
 }
 
@@ -597,7 +609,7 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
     }
     const bool many = c->n_spheres > PTR_FAST_MAX_SPHERES || (p->flags & PTR_DEBUG_FORCE_MANY);
     if (p->flags & PTR_MODE_F32_ONLY) {
-        HIP_TRY(c, many ? launch_render_many(a, n_frames, false, s) : launch_render_fast(a, n_frames, false, s));
+        HIP_TRY(c, many ? launch_render_many(a, n_frames, false, s) : launch_render_fast(a, n_frames, 0, s));
         if (timing) { HIP_TRY(c, hipEventRecord(c->ev[1], s)); c->timed_kernels = 1; }
         return mark_launch(c, s);
     }
@@ -633,7 +645,9 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
         c->hybrid_calls++;
         HIP_TRY(c, hipMemsetAsync(words + WORDS_STATS, 0, 256, s));
     }
-    hipError_t e = many ? launch_render_many(a, n_frames, true, s) : launch_render_fast(a, n_frames, true, s);
+    // (PTR_MODE_TOLERANT: the few-sphere kernel has a form of its own; the many-sphere kernel keeps every doubt)
+    hipError_t e = many ? launch_render_many(a, n_frames, true, s)
+                        : launch_render_fast(a, n_frames, (p->flags & PTR_MODE_TOLERANT) ? 2 : 1, s);
     if (e == hipSuccess && timing) e = hipEventRecord(c->ev[1], s);
     if (e == hipSuccess) {
         e = many ? launch_retrace_exact(a, 8, 8, s) : launch_retrace_exact(a, 1, 4, s);

@@ -40,7 +40,9 @@ struct alignas(16) FrameHeader {          // 128 bytes
     uint32_t needs_exact;                 // 1: scene has values the f32 path cannot represent
     double   bg64[3];
     float    bg32[3];
-    float    pad0;
+    float    tol_thr;                     // PTR_MODE_TOLERANT: a hit pixel whose summed error bounds of N.L (|error of N| + the sum
+                                          //   over the lights of |error of L|) exceed this is re-traced; below it the float32
+                                          //   colour is within 0.9 / 255 of the float64 one (host: build_frame_block)
     uint32_t off_g64, off_m64, off_p32, off_m32, off_lights, off_pad;   // byte offsets in block
     uint32_t self_skip;                   // 1: coordinates are small enough for the "own sphere never shadows" proof
     // planes and Phong terms (extension modes only, include/ptr.h "planes and Phong"); elements = spheres, then planes

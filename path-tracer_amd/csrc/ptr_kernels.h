@@ -10,8 +10,9 @@ hipError_t launch_render_exact(const RenderArgs& a, int n_frames, bool stats, hi
 hipError_t launch_retrace_exact(const RenderArgs& a, int parts1, int parts0, hipStream_t s);   // workgroups per sub-queue: shading-only entries / full re-traces
 hipError_t launch_trace_batch_exact(const TraceArgs& a, hipStream_t s);
 
-// float32 with uncertainty filter (ptr_kernels_fast.hip); hybrid = queue unsure pixels
-hipError_t launch_render_fast(const RenderArgs& a, int n_frames, bool hybrid, hipStream_t s);
+// float32 with uncertainty filter (ptr_kernels_fast.hip); mode 0: float32 only, 1: hybrid (queue every doubtful pixel: bytes
+// equal the reference's), 2: hybrid within one unit per channel (PTR_MODE_TOLERANT: queue the discontinuous doubts only)
+hipError_t launch_render_fast(const RenderArgs& a, int n_frames, int mode, hipStream_t s);
 int fast_kernel_rows_per_block();   // image rows / columns one workgroup of the float32 kernel covers
 int fast_kernel_cols_per_block();
 

@@ -54,19 +54,40 @@ struct Shade {
 };
 
 // the nearest element of the first lane, in the first pixel slot, that still waits in `rem` (wave-uniform; some lane waits)
+// (Scalar branches: a select between lane masks would turn them into per-lane values.  The slots are taken by a compile-time
+// recursion and every branch ends in an asm comment of its own: written as a loop over the slots, the compiler merges the
+// branches' v_readlane into one with a run-time slot number - and the whole px[] array then lives in scratch memory.)
+template <int P, int PPL>
+__device__ __forceinline__ int first_waiting_from(const unsigned long long (&rem)[PPL], const Pixel (&px)[PPL])
+{
+    if constexpr (P == PPL - 1) {
+        return __builtin_amdgcn_readlane(px[P].idx, (int)__builtin_ctzll(rem[P]));
+    } else {
+        if (rem[P] != 0ull) {
+            int r = __builtin_amdgcn_readlane(px[P].idx, (int)__builtin_ctzll(rem[P]));
+            asm volatile("; first_waiting: slot %1" : "+s"(r) : "i"(P));
+            return r;
+        }
+        return first_waiting_from<P + 1, PPL>(rem, px);
+    }
+}
 template <int PPL>
 __device__ __forceinline__ int first_waiting(const unsigned long long (&rem)[PPL], const Pixel (&px)[PPL])
 {
-    // (scalar branches: a select between lane masks would turn them into per-lane values)
-#pragma unroll
-    for (int p = 0; p < PPL - 1; p++)
-        if (rem[p] != 0ull) return __builtin_amdgcn_readlane(px[p].idx, (int)__builtin_ctzll(rem[p]));
-    return __builtin_amdgcn_readlane(px[PPL - 1].idx, (int)__builtin_ctzll(rem[PPL - 1]));
+    return first_waiting_from<0, PPL>(rem, px);
 }
 
-template <bool HYBRID, bool DBG, int PPL, bool GENERAL>
+// MODE 0: float32 only.  MODE 1: hybrid, bytes equal the reference's (every doubt, the 8-bit rounding included, is re-done
+// in float64).  MODE 2: hybrid within the tolerance of one unit per channel (PTR_MODE_TOLERANT): only the DISCONTINUOUS
+// doubts (hit/miss, nearest-vs-second, far clip, shadow any-hit) are re-traced; the rounding doubt, the per-light sums of
+// error bounds behind it and the shading-only re-do are gone, and one compare per pixel keeps the promise: the sum of the
+// error bounds of N and of every L must stay below the frame's threshold (FrameHeader::tol_thr: the float32 colour is then
+// within one 8-bit unit of the float64 one before rounding, so the rounded bytes differ by at most 1).
+template <int MODE, bool DBG, int PPL, bool GENERAL>
 __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_per_eu(PTR_FAST_WAVES))) render_fast_kernel(RenderArgs a)
 {
+    constexpr bool HYBRID = MODE != 0;
+    constexpr bool TOL = MODE == 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int frame = blockIdx.z;
     const uint64_t frame_px = (uint64_t)a.width * (uint64_t)a.scan_height;
@@ -279,6 +300,8 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
         const volatile uint32_t PTR_CONST* hw = (const volatile uint32_t PTR_CONST*)(uintptr_t)block;
         const int nl = (int)hw[offsetof(FrameHeader, n_lights) / 4];
         const bool self_ok = hw[offsetof(FrameHeader, self_skip) / 4] != 0u;
+        [[maybe_unused]] float tol_thr = 0.0f;
+        if constexpr (TOL) tol_thr = __uint_as_float(hw[offsetof(FrameHeader, tol_thr) / 4]);
         const float4* lane_pairs = reinterpret_cast<const float4*>(block + a.off_pairs) + li;
         float4 pq = load_f4(lane_pairs);
         const F3 cj = load_f3(&gp32[li].lx);
@@ -351,8 +374,11 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
                         // P - C (Sphere.js:47-51), normalised by 1 / r: the true hit point lies ON the sphere, so this differs
                         // from the true normal by (error of P) / r, which eN below already counts
                         s.N = F3{(s.P.x - W.g0.x) * sg, (s.P.y - W.g0.y) * sg, (s.P.z - W.g0.z) * sg};
-                        s.eN = fmaf(s.eP + EPS * (lnorm_w + s.t), inv_r, 15.0f * EPS);  // |error of N| (1 / r itself: 2 eps), + 10 eps for
-                                                                                        //   the rounding of N.L and of the sums over the lights
+                        if constexpr (TOL)
+                            s.eN = (s.eP + EPS * (lnorm_w + s.t)) * inv_r;              // (the constant terms are in tol_thr; the lights add their eL to this)
+                        else
+                            s.eN = fmaf(s.eP + EPS * (lnorm_w + s.t), inv_r, 15.0f * EPS);  // |error of N| (1 / r itself: 2 eps), + 10 eps for
+                                                                                            //   the rounding of N.L and of the sums over the lights
                     }
                 }
                 unsigned long long left = 0ull;
@@ -437,7 +463,7 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
                 const unsigned long long certain = ballot(bj > ebj) & ballot(disc > band);
                 const unsigned long long possible = ballot(bj >= -ebj) & ballot(disc >= -band);
                 s.maybe_m |= possible & ~certain;
-                if constexpr (HYBRID) px[p].idx |= lane_of(certain & s.open_m) ? (int)(0x100u << (2 * k)) : 0;
+                if constexpr (HYBRID && !TOL) px[p].idx |= lane_of(certain & s.open_m) ? (int)(0x100u << (2 * k)) : 0;
                 if constexpr (!HYBRID)                 // the float32 verdict only shows in f32-only output
                     s.blocked_m |= ballot(bj >= 0.0f) & ballot(disc >= 0.0f);
                 s.open_m &= ~certain;
@@ -522,15 +548,21 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
                 // A "maybe" only matters if no certain hit blocks the light anyway.  N.L within its error of 0 is a
                 // "maybe" too: the float64 value may be positive where this one is not, and then the light counts.
                 unsure[p].add_mask(s.open_m & s.maybe_m, WHY_SHADOW);
-                const float enl = s.eN + s.eL;                 // |error of N.L| (the rounding of the dot and of the sums is in eN)
-                if constexpr (HYBRID) unsure[p].add_mask(ballot(fabsf(s.ratio) <= enl) & s.valid_m, WHY_SHADOW);
                 // branch-free: an unlit lane adds zeros (selects cost less than switching lanes off and on again)
                 const bool lit = lane_of(s.open_m & ~s.blocked_m);
                 const float wr = lit ? s.ratio : 0.0f;
                 s.ar = fmaf(ler, wr, s.ar);
                 s.ag = fmaf(leg, wr, s.ag);
                 s.ab = fmaf(leb, wr, s.ab);
-                s.werr = fmaf(lit ? lemax : 0.0f, enl, s.werr);
+                if constexpr (TOL) {
+                    // N.L is off by at most eN + eL, whether the light counts or not (a float32 N.L <= 0 whose float64 value
+                    // is positive adds at most that much too): the bounds are summed, the sum is compared once per pixel
+                    s.eN += s.eL;
+                } else {
+                    const float enl = s.eN + s.eL;             // |error of N.L| (the rounding of the dot and of the sums is in eN)
+                    if constexpr (HYBRID) unsure[p].add_mask(ballot(fabsf(s.ratio) <= enl) & s.valid_m, WHY_SHADOW);
+                    s.werr = fmaf(lit ? lemax : 0.0f, enl, s.werr);
+                }
             }
             // the next light's record and pre-filter row (the tables end with a padding record / row)
             lrp += 3; pairs += pstride; lane_row += pstride;
@@ -538,6 +570,11 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
             pq = load_f4(lane_row);
         }
 
+        if constexpr (TOL) {
+            // the one check of the tolerance mode: the summed error bounds of N.L over the lights against the frame's threshold
+#pragma unroll
+            for (int p = 0; p < PPL; p++) unsure[p].add_mask(ballot(sh[p].eN > tol_thr) & sh[p].valid_m, WHY_ROUND);
+        }
         stamp(5);
         // the background (RayTracer.js:43-46, bit-exact by construction) is read only here: four SGPRs fewer to carry
         const uint32_t bg_packed = hdr->bg_packed;
@@ -550,7 +587,7 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
             any_value(cr[p]); any_value(cg[p]); any_value(cb[p]);
             // HYBRID: a pixel in doubt for any reason OTHER than its rounding is re-traced from scratch (bit 9 of its idx
             // register: one lane mask, not two, stays in SGPRs); one that is only here for its rounding gets the shading-only re-do
-            if constexpr (HYBRID) px[p].idx |= unsure[p].any() ? 0x200 : 0;
+            if constexpr (HYBRID && !TOL) px[p].idx |= unsure[p].any() ? 0x200 : 0;
         }
         const ConstF4 mat0 = (ConstF4)(uintptr_t)(block + a.off_m32);
         {
@@ -564,7 +601,7 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
                 load_f8(mat0 + 2u * (unsigned)w, mlo, mhi);
                 unsigned long long m[PPL];
 #pragma unroll
-                for (int p = 0; p < PPL; p++) { m[p] = ballot((px[p].idx & 0xFF) == w); rem[p] &= ~m[p]; }
+                for (int p = 0; p < PPL; p++) { m[p] = ballot((TOL ? px[p].idx : (px[p].idx & 0xFF)) == w); rem[p] &= ~m[p]; }
                 arrive(mlo); arrive(mhi);
 #pragma unroll
                 for (int p = 0; p < PPL; p++) {
@@ -572,14 +609,16 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
                     if (lane_of(m[p])) {
                         const Shade& s = sh[p];
                         const float hr = fmaf(mlo.x, s.ar, mhi.x), hg = fmaf(mlo.y, s.ag, mhi.y), hb = fmaf(mlo.z, s.ab, mhi.z);
-                        // |error of N.L| <= eN + eL (+ rounding of the dot and of the sums, 8 eps)
-                        const float band = 255.0f * fmaf(mlo.w, s.werr, 4.0f * EPS * mhi.w) + 2e-5f;
                         // Math.round(v) = floor(v + 0.5); v + 0.5 is exact in float32 for 0.5 <= v < 256, and below 0.5 it can only
                         // round across 1.0 within the band that is re-traced anyway
                         const float vr = fmin_raw(hr, 1.0f) * 255.0f, vg = fmin_raw(hg, 1.0f) * 255.0f, vb = fmin_raw(hb, 1.0f) * 255.0f;
-                        const float qr = __builtin_amdgcn_fractf(vr) - 0.5f, qg = __builtin_amdgcn_fractf(vg) - 0.5f,
-                                    qb = __builtin_amdgcn_fractf(vb) - 0.5f;
-                        rdoubt[p] = fminf(fminf(fabsf(qr), fabsf(qg)), fabsf(qb)) - band;
+                        if constexpr (!TOL) {
+                            // |error of N.L| <= eN + eL (+ rounding of the dot and of the sums, 8 eps)
+                            const float band = 255.0f * fmaf(mlo.w, s.werr, 4.0f * EPS * mhi.w) + 2e-5f;
+                            const float qr = __builtin_amdgcn_fractf(vr) - 0.5f, qg = __builtin_amdgcn_fractf(vg) - 0.5f,
+                                        qb = __builtin_amdgcn_fractf(vb) - 0.5f;
+                            rdoubt[p] = fminf(fminf(fabsf(qr), fabsf(qg)), fabsf(qb)) - band;
+                        }
                         const uint32_t r8 = (uint32_t)(vr + 0.5f), g8 = (uint32_t)(vg + 0.5f), b8 = (uint32_t)(vb + 0.5f);
                         packed[p] = (255u << 24) | (b8 << 16) | (g8 << 8) | r8;
                         cr[p] = hr; cg[p] = hg; cb[p] = hb;
@@ -592,7 +631,8 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
             }
         }
 #pragma unroll
-        for (int p = 0; p < PPL; p++) unsure[p].add_mask(ballot(rdoubt[p] <= 0.0f), WHY_ROUND);   // (lanes without a hit hold 1)
+        for (int p = 0; p < PPL; p++)
+            if constexpr (!TOL) unsure[p].add_mask(ballot(rdoubt[p] <= 0.0f), WHY_ROUND);   // (lanes without a hit hold 1)
     } else {
 #pragma unroll
         for (int p = 0; p < PPL; p++) { cr[p] = 0.0f; cg[p] = 0.0f; cb[p] = 0.0f; shaded_m[p] = 0ull; packed[p] = hdr->bg_packed; }
@@ -626,7 +666,7 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
         if constexpr (HYBRID) {
             if (unsure[p].mask == 0ull) continue;      // wave-uniform: nearly every wave leaves here
             const bool may = st8 | (in_img & (a.out32f != nullptr));
-            const bool full = (r.idx & 0x200) != 0 || r.idx < 0;      // (a miss has nothing to re-shade)
+            const bool full = TOL || (r.idx & 0x200) != 0 || r.idx < 0;      // (a miss has nothing to re-shade; the tolerance mode has no re-shade)
             if (unsure[p].any() & may) {
                 // one counter word would saturate (~88 returning atomics/us chip-wide): the queue is
                 // cut into n_queues sub-queues, each with its own counter line, chosen by workgroup
@@ -653,29 +693,30 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
     }
 }
 
-template <bool HYBRID, bool DBG, int PPL, bool GENERAL>
+template <int MODE, bool DBG, int PPL, bool GENERAL>
 static hipError_t launch_camera(const RenderArgs& a, int n_frames, hipStream_t s)
 {
     const int tw = PTR_FAST_BLOCK / 64 * 8 * PPL;
     dim3 grid((a.width + tw - 1) / tw, (a.scan_height + PTR_TILE_H - 1) / PTR_TILE_H, n_frames);
-    hipLaunchKernelGGL((render_fast_kernel<HYBRID, DBG, PPL, GENERAL>), grid, dim3(PTR_FAST_BLOCK), 0, s, a);
+    hipLaunchKernelGGL((render_fast_kernel<MODE, DBG, PPL, GENERAL>), grid, dim3(PTR_FAST_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 
-template <bool HYBRID, bool DBG, int PPL>
+template <int MODE, bool DBG, int PPL>
 static hipError_t launch_variant(const RenderArgs& a, int n_frames, hipStream_t s)
 {
-    return a.cam.general ? launch_camera<HYBRID, DBG, PPL, true>(a, n_frames, s) : launch_camera<HYBRID, DBG, PPL, false>(a, n_frames, s);
+    return a.cam.general ? launch_camera<MODE, DBG, PPL, true>(a, n_frames, s) : launch_camera<MODE, DBG, PPL, false>(a, n_frames, s);
 }
 
 int fast_kernel_rows_per_block() { return PTR_TILE_H; }
 int fast_kernel_cols_per_block() { return PTR_FAST_BLOCK / 64 * 8 * PTR_FAST_PPL; }
 
-hipError_t launch_render_fast(const RenderArgs& a, int n_frames, bool hybrid, hipStream_t s)
+hipError_t launch_render_fast(const RenderArgs& a, int n_frames, int mode, hipStream_t s)
 {
-    if (hybrid) return launch_variant<true, false, PTR_FAST_PPL>(a, n_frames, s);
-    if (a.flags & 0x8000u /* PTR_DEBUG_REASONS */) return launch_variant<false, true, PTR_FAST_PPL>(a, n_frames, s);
-    return launch_variant<false, false, PTR_FAST_PPL>(a, n_frames, s);
+    if (mode == 2) return launch_variant<2, false, PTR_FAST_PPL>(a, n_frames, s);
+    if (mode == 1) return launch_variant<1, false, PTR_FAST_PPL>(a, n_frames, s);
+    if (a.flags & 0x8000u /* PTR_DEBUG_REASONS */) return launch_variant<0, true, PTR_FAST_PPL>(a, n_frames, s);
+    return launch_variant<0, false, PTR_FAST_PPL>(a, n_frames, s);
 }
 
 }  // namespace ptr

@@ -15,6 +15,7 @@ LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libptr_hip.s
 QUIRK_ROW_SHIFT = 0x0001
 MODE_EXACT_F64 = 0x0002
 MODE_F32_ONLY = 0x0004
+MODE_TOLERANT = 0x0020
 FLAG_STATS = 0x0008
 FLAG_TIMING = 0x0010
 DEBUG_REASONS = 0x8000

@@ -10,7 +10,7 @@ from bench import example1_soa, WIDTH, HEIGHT
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-mode = {"hybrid": 0, "f32": ptr_amd.MODE_F32_ONLY, "exact": ptr_amd.MODE_EXACT_F64,
+mode = {"hybrid": 0, "tol": ptr_amd.MODE_TOLERANT, "f32": ptr_amd.MODE_F32_ONLY, "exact": ptr_amd.MODE_EXACT_F64,
         "hybrid_many": ptr_amd.DEBUG_FORCE_MANY, "f32_many": ptr_amd.MODE_F32_ONLY | ptr_amd.DEBUG_FORCE_MANY}[sys.argv[3] if len(sys.argv) > 3 else "hybrid"]
 soa = example1_soa()
 if len(sys.argv) > 4 and sys.argv[4] == "many":
