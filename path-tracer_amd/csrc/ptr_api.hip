@@ -341,7 +341,7 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
     for (int k = 0; k < nl; k++) {
         const SphereP32& p = p32[lights[k]];
         const SphereM32& m = m32[lights[k]];
-        lrec[k] = LightRec{p.lx, p.ly, p.lz, p.lnorm, m.er, m.eg, m.eb, m.emax, lights[k], {0, 0, 0}};
+        lrec[k] = LightRec{p.lx, p.ly, p.lz, p.lnorm, m.er, m.eg, m.eb, m.emax, lights[k], (float)EPS32 * p.lnorm * 1.0000002f, {0, 0}};
     }
     for (int k = 0; k < 3; k++) {
         h->bg64[k] = bg[k];
@@ -511,20 +511,22 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
 
     RenderArgs a;
     std::memset(&a, 0, sizeof a);
-    a.scenes = static_cast<const unsigned char*>(c->scenes.ptr);
+    // (the kernels see the call's first frame as frame 0; the few-sphere kernel counts on a call's blocks spanning < 4 GB)
+    a.scenes = static_cast<const unsigned char*>(c->scenes.ptr) + (size_t)first_frame * c->frame_stride;
     a.frame_stride = c->frame_stride;
     {
         const BlockLayout L = block_layout(c->n_spheres);
         a.off_p32 = L.off_p32; a.off_m32 = L.off_m32; a.off_lights = L.off_lights; a.off_pairs = L.off_pairs; a.off_lrec = L.off_lrec; a.off_cull = L.off_cull; a.off_x4 = L.off_x4;
         a.n = c->n_spheres;
     }
-    a.first_frame = first_frame;
+    a.first_frame = 0;
     a.n_frames = n_frames;
     a.width = p->width; a.height = p->height; a.start_y = p->start_y; a.scan_height = p->scan_height;
     a.flags = p->flags;
     a.strip_h = strips ? strips->strip_height : 1;
     a.n_parts = strips ? strips->n_parts : 1;
     a.part = strips ? strips->part : 0;
+    a.rows_mode = a.n_parts <= 1 ? 0 : (a.strip_h % PTR_TILE_H == 0 ? 1 : 2);
     a.out_frame_stride = frame_stride_px ? frame_stride_px : (uint64_t)p->width * (uint64_t)p->scan_height;
     for (int k = 0; k < 3; k++) {
         a.cam.org[k] = c->cam.origin[k];
@@ -550,7 +552,8 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
         const double nx = R[1] * U[2] - R[2] * U[1], ny = R[2] * U[0] - R[0] * U[2], nz = R[0] * U[1] - R[1] * U[0];
         const double nn = std::sqrt(nx * nx + ny * ny + nz * nz);
         const double dmin = nn > 0 ? std::fabs(F[0] * nx + F[1] * ny + F[2] * nz) / nn : 0.0;
-        const double rho = (4.0 * PTR_FAST_PPL - 0.5) * std::fabs((double)a.camf.sx) * std::sqrt(R[0] * R[0] + R[1] * R[1] + R[2] * R[2]) +
+        const int fast_mode = (p->flags & PTR_MODE_F32_ONLY) ? 0 : ((p->flags & PTR_MODE_TOLERANT) ? 2 : 1);
+        const double rho = (4.0 * fast_kernel_ppl(fast_mode) - 0.5) * std::fabs((double)a.camf.sx) * std::sqrt(R[0] * R[0] + R[1] * R[1] + R[2] * R[2]) +
                            (0.5 * PTR_TILE_H - 0.5) * std::fabs((double)a.camf.sy) * std::sqrt(U[0] * U[0] + U[1] * U[1] + U[2] * U[2]);
         const double sn = dmin > 0 ? 1.02 * rho / dmin + 1e-6 : 2.0;
         const bool rows_consecutive = a.n_parts <= 1 || a.strip_h % PTR_TILE_H == 0;
@@ -608,6 +611,8 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
         return mark_launch(c, s);
     }
     const bool many = c->n_spheres > PTR_FAST_MAX_SPHERES || (p->flags & PTR_DEBUG_FORCE_MANY);
+    if (!many && (uint64_t)n_frames * (uint64_t)c->frame_stride >= (1ull << 32))
+        return fail(c, PTR_ERR_INVALID, "internal: %d frame blocks of %zu bytes span 4 GB or more", n_frames, c->frame_stride);
     if (p->flags & PTR_MODE_F32_ONLY) {
         HIP_TRY(c, many ? launch_render_many(a, n_frames, false, s) : launch_render_fast(a, n_frames, 0, s));
         if (timing) { HIP_TRY(c, hipEventRecord(c->ev[1], s)); c->timed_kernels = 1; }
@@ -615,7 +620,7 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
     }
     // hybrid: float32 kernel fills the sub-queues, float64 kernel drains them
     const int rpb = many ? many_kernel_rows_per_block() : fast_kernel_rows_per_block();
-    const int cpb = many ? PTR_TILE_W : fast_kernel_cols_per_block();
+    const int cpb = many ? PTR_TILE_W : fast_kernel_cols_per_block((p->flags & PTR_MODE_TOLERANT) ? 2 : 1);
     const uint64_t n_blocks = (uint64_t)((p->width + cpb - 1) / cpb) *
                               (uint64_t)((p->scan_height + rpb - 1) / rpb) * (uint64_t)n_frames;
     uint64_t n_queues = 1;                                     // a power of two (the kernel masks)

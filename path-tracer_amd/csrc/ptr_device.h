@@ -22,6 +22,10 @@
 #ifndef PTR_FAST_WAVES
 #define PTR_FAST_WAVES 6          // waves per SIMD the float32 kernel's register allocation aims at (80 VGPRs)
 #endif
+#ifndef PTR_FAST_PPL_TOL
+#define PTR_FAST_PPL_TOL 4        // PTR_MODE_TOLERANT: 4 pixels per lane (wave tile 32 x 8) at 5 waves per SIMD (96 VGPRs): measured -3.4 %
+#endif                            //   against 3 pixels at 6 waves (the per-wave work - culling, cones, scalar bookkeeping - is shared by more pixels)
+#define PTR_FAST_WAVES_WIDE 5
 #define PTR_MAX_QUEUES 1024       // sub-queues of the hybrid mode's re-trace queue
 #define PTR_MAX_PAIR_LIGHTS 64     // lights with a shadow pre-filter table (more lights: no culling for them)
 #define PTR_FAST_MAX_SPHERES 12    // up to this many spheres: ptr_kernels_fast.hip; more: ptr_kernels_many.hip (measured
@@ -98,7 +102,7 @@ static_assert(sizeof(PlaneG64) == 48 && sizeof(PlaneP32) == 32, "plane record la
 struct alignas(16) PairQ { float ax, ay, az, thr; };
 // What the few-sphere kernel needs of light k, at an address that does not depend on loaded data (the element record
 // behind lights[k] costs two dependent scalar loads): [n_lights + 1], the last record is zero padding.
-struct alignas(16) LightRec { float lx, ly, lz, lnorm; float er, eg, eb, emax; int32_t index; int32_t pad[3]; };
+struct alignas(16) LightRec { float lx, ly, lz, lnorm; float er, eg, eb, emax; int32_t index; float eps_lnorm; int32_t pad[2]; };   // eps_lnorm = 2^-24 lnorm
 static_assert(sizeof(LightRec) == 48, "LightRec layout");
 // Tile culling of the few-sphere kernel, read by lane i for sphere i: a ray of a cone (axis dc, half-angle T) around the
 // wave tile's centre ray can reach sphere i, or the error band of its float32 hit test, only if
@@ -162,6 +166,8 @@ struct RenderArgs {
     int32_t   width, height, start_y, scan_height;
     uint32_t  flags;                 // PTR_QUIRK_ROW_SHIFT etc. (include/ptr.h)
     int32_t   strip_h, n_parts, part; // cyclic strips: local row r is image row global_y(r); n_parts 1 = band
+    int32_t   rows_mode;             // few-sphere kernel: 0 = band (row = start_y + local row), 1 = strips of a multiple of 8 rows (a tile's
+                                     //   rows are consecutive image rows), 2 = any strips (a division per lane)
     uint64_t  out_frame_stride;      // pixels between consecutive frames in out8 / out32f
     CameraArgs cam;
     CameraF32  camf;

@@ -60,9 +60,15 @@ __device__ __forceinline__ P32H load_p32h(ConstF4 rec, ConstF4 pair) { P32H q; l
 // the 8 leading floats alone
 __device__ __forceinline__ P32G load_p32g(ConstF4 rec) { P32G q; load_f8(rec, q.g0, q.g1); return q; }
 // light k's record (LightRec)
-struct LightQ { f4 g, e; int32_t index; };
+struct LightQ { f4 g, e; int32_t index; float eps_lnorm; };
+typedef float f2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ LightQ load_light(ConstF4 rec)
-{ LightQ q; load_f8(rec, q.g, q.e); q.index = *reinterpret_cast<const volatile int32_t PTR_CONST*>(rec + 2); return q; }
+{
+    LightQ q; load_f8(rec, q.g, q.e);
+    const f2v t = *reinterpret_cast<const volatile f2v PTR_CONST*>(rec + 2);      // index (bits), eps |l|
+    q.index = __builtin_bit_cast(int32_t, t[0]); q.eps_lnorm = t[1];
+    return q;
+}
 #define PTR_F4_IN(v) "s"((v).x), "s"((v).y), "s"((v).z), "s"((v).w)
 __device__ __forceinline__ void arrive(const P32Q& q)
 { asm volatile("" ::PTR_F4_IN(q.g0), PTR_F4_IN(q.g1), PTR_F4_IN(q.g2)); }
@@ -75,7 +81,7 @@ __device__ __forceinline__ void arrive(const P32G& q)
 __device__ __forceinline__ void arrive(const f4& q)
 { asm volatile("" ::PTR_F4_IN(q)); }
 __device__ __forceinline__ void arrive(const LightQ& q)
-{ asm volatile("" ::PTR_F4_IN(q.g), PTR_F4_IN(q.e), "s"(q.index)); }
+{ asm volatile("" ::PTR_F4_IN(q.g), PTR_F4_IN(q.e), "s"(q.index), "s"(q.eps_lnorm)); }
 __device__ __forceinline__ void arrive(const P32H& q)
 { asm volatile("" ::PTR_F4_IN(q.g0), PTR_F4_IN(q.g1), PTR_F4_IN(q.pa)); }
 __device__ __forceinline__ void arrive_after(const P32H& q, unsigned long long dep)

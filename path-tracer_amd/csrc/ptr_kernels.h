@@ -13,8 +13,9 @@ hipError_t launch_trace_batch_exact(const TraceArgs& a, hipStream_t s);
 // float32 with uncertainty filter (ptr_kernels_fast.hip); mode 0: float32 only, 1: hybrid (queue every doubtful pixel: bytes
 // equal the reference's), 2: hybrid within one unit per channel (PTR_MODE_TOLERANT: queue the discontinuous doubts only)
 hipError_t launch_render_fast(const RenderArgs& a, int n_frames, int mode, hipStream_t s);
+int fast_kernel_ppl(int mode);      // pixels per lane of the float32 kernel in that mode
 int fast_kernel_rows_per_block();   // image rows / columns one workgroup of the float32 kernel covers
-int fast_kernel_cols_per_block();
+int fast_kernel_cols_per_block(int mode);
 
 // float32 for many spheres: sphere list staged through LDS, two-level tests (ptr_kernels_many.hip)
 hipError_t launch_render_many(const RenderArgs& a, int n_frames, bool hybrid, hipStream_t s);

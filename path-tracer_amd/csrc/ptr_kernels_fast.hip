@@ -44,11 +44,11 @@ struct Shade {
     unsigned long long valid_m; // ... as a lane mask
     int   self;                 // the element the pixel lies on, seen from outside (-1: none / seen from inside)
     F3    P, N;                 // hit point, normal (camera-relative)
-    float t, eP, eN;
+    float t, eP, eN;            // eP: |error of P| + eps t (every use adds eps t, or may)
     float ar, ag, ab, werr;          // sum over the unblocked lights of emission * N.L per channel; of (largest emission
                                      //   channel) * (error bound of that light's N.L)
     // per light
-    F3    L;
+    float invl;                 // 1 / |light - P| (the unit vector itself is worked out inside the few occluder tests)
     float ratio, eL;            // N.L, |error of L| (+ 3 eps: see the pre-filter)
     unsigned long long open_m, maybe_m, blocked_m;
 };
@@ -83,8 +83,10 @@ __device__ __forceinline__ int first_waiting(const unsigned long long (&rem)[PPL
 // error bounds behind it and the shading-only re-do are gone, and one compare per pixel keeps the promise: the sum of the
 // error bounds of N and of every L must stay below the frame's threshold (FrameHeader::tol_thr: the float32 colour is then
 // within one 8-bit unit of the float64 one before rounding, so the rounded bytes differ by at most 1).
-template <int MODE, bool DBG, int PPL, bool GENERAL>
-__global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_per_eu(PTR_FAST_WAVES))) render_fast_kernel(RenderArgs a)
+// QUIRK: PTR_QUIRK_ROW_SHIFT (a kernel of its own: the throughput paths never pay for the test).
+template <int MODE, bool DBG, int PPL, bool GENERAL, bool QUIRK>
+__global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_per_eu(PPL >= 4 ? PTR_FAST_WAVES_WIDE : PTR_FAST_WAVES)))
+render_fast_kernel(RenderArgs a)
 {
     constexpr bool HYBRID = MODE != 0;
     constexpr bool TOL = MODE == 2;
@@ -92,9 +94,11 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
     const int frame = blockIdx.z;
     const uint64_t frame_px = (uint64_t)a.width * (uint64_t)a.scan_height;
     uint32_t* out8 = a.out8 + frame * a.out_frame_stride;
-    const bool quirk = (a.flags & 0x0001u) != 0;      // PTR_QUIRK_ROW_SHIFT
+    constexpr bool quirk = QUIRK;                     // PTR_QUIRK_ROW_SHIFT
 
-    const unsigned char* block = a.scenes + (uint64_t)(a.first_frame + frame) * a.frame_stride;
+    // (the host passes `scenes` at the call's first frame and vouches that a call's frame blocks span less than 4 GB: few
+    // spheres, at most 65 535 frames)
+    const unsigned char* block = a.scenes + (uint32_t)((uint32_t)frame * (uint32_t)a.frame_stride);
     const ConstHeader hdr = (ConstHeader)(uintptr_t)block;
     const ConstF4 rec0 = (ConstF4)(uintptr_t)(block + a.off_p32);          // uniform reads, 4 f4 per sphere
     const ConstF4 pairs0 = (ConstF4)(uintptr_t)(block + a.off_pairs);      // [light][pair_stride(n)] pre-filter records
@@ -119,11 +123,15 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
     // wave-uniform value worked out on the scalar side, plus the lane's row in the tile.
     const int tile_row0 = blockIdx.y * PTR_TILE_H;
     int gy0 = 0, gy;
-    if (a.n_parts <= 1 || a.strip_h % PTR_TILE_H == 0) {
+    if (a.rows_mode == 0) {                        // a band: the common case first, two scalar instructions
+        gy0 = a.start_y + tile_row0;
+        gy = gy0 + (lane >> 3);
+    } else if (a.rows_mode == 1) {                 // strips of a multiple of 8 rows
+        asm volatile("");                          // (keeps this a branch: the compiler would compute both forms and select)
         gy0 = global_y(a, tile_row0);
         gy = gy0 + (lane >> 3);
     } else {
-        asm volatile("");                          // (keeps this a branch: the compiler would compute both forms and select)
+        asm volatile("");
         gy = global_y(a, tile_row0 + (lane >> 3));
     }
     // camera ray of a pixel slot (RayTracer.js:171-174)
@@ -155,13 +163,15 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
         for (int p = 0; p < PPL; p++) any_live |= px[p].live;
         if (ballot(any_live) == 0ull) return;          // wave-uniform exit: the whole wave is outside
     }
-    if (quirk && blockIdx.y == 0) {
-        // PTR_QUIRK_ROW_SHIFT (RayTracer.js:169): the last row of the band is never written by a pixel; the waves of the
-        // first tile row clear it.  (A wave-uniform branch that the other waves jump over; the empty asm keeps it one.)
-        asm volatile("");
+    if constexpr (QUIRK) {
+        if (blockIdx.y == 0) {
+            // PTR_QUIRK_ROW_SHIFT (RayTracer.js:169): the last row of the band is never written by a pixel; the waves of the
+            // first tile row clear it.  (A wave-uniform branch that the other waves jump over; the empty asm keeps it one.)
+            asm volatile("");
 #pragma unroll
-        for (int p = 0; p < PPL; p++)
-            if (px[p].live & (px[p].row == 0)) out8[(uint64_t)a.width * (a.scan_height - 1) + px[p].x] = 0u;
+            for (int p = 0; p < PPL; p++)
+                if (px[p].live & (px[p].row == 0)) out8[(uint64_t)a.width * (a.scan_height - 1) + px[p].x] = 0u;
+        }
     }
 
     stamp(1);
@@ -333,6 +343,7 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
                 for (int p = 0; p < PPL; p++) { m[p] = ballot(px[p].idx == w); rem[p] &= ~m[p]; }
                 arrive(W);
                 const float cc_w = W.g0.w, r2_w = W.g1.z, lnorm_w = W.g1.w, eb_w = W.g2.w, inv_r = W.g3.x;
+                const float el_w = EPS * lnorm_w;          // (wave-uniform: once per trip)
                 const bool form_b = __float_as_int(W.g3.y) < 0;        // wave-uniform (the host's flag: see SphereP32::hed)
                 const float hed_w = __int_as_float(__float_as_int(W.g3.y) & 0x7fffffff);
                 const bool outside = cc_w > 0.0f;          // wave-uniform: a scalar branch, not selects
@@ -362,11 +373,11 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
                         if (outside) {
                             s.self = w;
                             s.t = cc_w * rbt;
-                            s.eP = s.t * fmaf(et_w, rbt, 4.0f * EPS);  // |error of P|
+                            s.eP = s.t * fmaf(et_w, rbt, 5.0f * EPS);  // |error of P| + eps t
                             sg = inv_r;
                         } else {
                             s.t = bt;
-                            s.eP = fmaf(2.0f * EPS, s.t, et_w);
+                            s.eP = fmaf(3.0f * EPS, s.t, et_w);
                             sg = -inv_r;                               // inside: d.N > 0 -> revert (RayTracer.js:54-58)
                         }
                         // ---- hit frame (RayTracer.js:48-58), camera-relative -------------------------------
@@ -375,10 +386,10 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
                         // from the true normal by (error of P) / r, which eN below already counts
                         s.N = F3{(s.P.x - W.g0.x) * sg, (s.P.y - W.g0.y) * sg, (s.P.z - W.g0.z) * sg};
                         if constexpr (TOL)
-                            s.eN = (s.eP + EPS * (lnorm_w + s.t)) * inv_r;              // (the constant terms are in tol_thr; the lights add their eL to this)
+                            s.eN = (s.eP + el_w) * inv_r;                               // (the constant terms are in tol_thr; the lights add their eL to this)
                         else
-                            s.eN = fmaf(s.eP + EPS * (lnorm_w + s.t), inv_r, 15.0f * EPS);  // |error of N| (1 / r itself: 2 eps), + 10 eps for
-                                                                                            //   the rounding of N.L and of the sums over the lights
+                            s.eN = fmaf(s.eP + el_w, inv_r, 15.0f * EPS);               // |error of N| = (|error of P| + eps (|l| + t)) / r (1 / r itself:
+                                                                                        //   2 eps), + 10 eps for the rounding of N.L and of the sums over the lights
                     }
                 }
                 unsigned long long left = 0ull;
@@ -422,6 +433,7 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
         // ptr_kernels_exact.hip reshade_exact): light k "certainly blocked" = bit 8 + 2k of the lane's idx register
         // (n <= 12: the index itself fits the low byte); k is the light being worked on.
         int k = 0;
+        F3 lpos_k{0.0f, 0.0f, 0.0f};                      // light k's position (wave-uniform)
         auto shadow = [&](const P32H& pj, int j) {
             if constexpr (DBG) dbg_pre_tests++;
             // Pre-filter: the shadow ray leaves (within the 1e-4 bias) along the line through the
@@ -429,10 +441,13 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
             // the error of L added on the safe side.  Most (light, element) pairs fail this for every
             // lane of the wave, and the whole test below is skipped.
             unsigned long long near_m = 0ull, pass_m[PPL];
+            // the unit vector towards the light, rebuilt per test: few waves get here, and PPL x 3 registers stay free
+            auto unit_L = [&](const Shade& s) { return F3{(lpos_k.x - s.P.x) * s.invl, (lpos_k.y - s.P.y) * s.invl, (lpos_k.z - s.P.z) * s.invl}; };
 #pragma unroll
             for (int p = 0; p < PPL; p++) {
                 const Shade& s = sh[p];
-                const float c = fmaf(pj.pa.z, s.L.z, fmaf(pj.pa.y, s.L.y, pj.pa.x * s.L.x));
+                const F3 L = unit_L(s);
+                const float c = fmaf(pj.pa.z, L.z, fmaf(pj.pa.y, L.y, pj.pa.x * L.x));
                 pass_m[p] = ballot(fabsf(c) + s.eL >= pj.pa.w) & s.open_m;   // thr carries 8 more eps of slack
                 near_m |= pass_m[p];
             }
@@ -451,7 +466,7 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
                 const F3 so{fmaf(s.N.x, (float)PTR_BIAS, s.P.x), fmaf(s.N.y, (float)PTR_BIAS, s.P.y),
                             fmaf(s.N.z, (float)PTR_BIAS, s.P.z)};
                 const F3 lj{pj.g0.x - so.x, pj.g0.y - so.y, pj.g0.z - so.z};
-                const float bj = dot3(lj, s.L);
+                const float bj = dot3(lj, unit_L(s));
                 const float ll = dot3(lj, lj);
                 const float disc = fmaf(bj, bj, pj.g1.z - ll);
                 // error bounds: |lj| <= A, 4 d(lj) <= dlj4, d(bj) <= ebj, d(disc) <= band
@@ -523,16 +538,17 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
             arrive(lq);
             const unsigned i = (unsigned)lq.index & 15u;       // (the mask tells the compiler that the index is small)
             const F3 lpos{lq.g.x, lq.g.y, lq.g.z};
+            lpos_k = lpos;
             const float llnorm = lq.g.w;
             const float ler = lq.e.x, leg = lq.e.y, leb = lq.e.z, lemax = lq.e.w;
+            const float el_l = lq.eps_lnorm;                   // eps |l| of the light (host)
 #pragma unroll
             for (int p = 0; p < PPL; p++) {
                 Shade& s = sh[p];
-                F3 L{lpos.x - s.P.x, lpos.y - s.P.y, lpos.z - s.P.z};
-                const float invl = rsq(dot3(L, L));
-                s.L = F3{L.x * invl, L.y * invl, L.z * invl};
-                s.eL = fmaf(fmaf(EPS, llnorm + s.t, s.eP), invl, 3.0f * EPS);   // |error of L|
-                s.ratio = dot3(s.N, s.L);
+                const F3 L{lpos.x - s.P.x, lpos.y - s.P.y, lpos.z - s.P.z};
+                s.invl = rsq(dot3(L, L));
+                s.eL = fmaf(s.eP + el_l, s.invl, 3.0f * EPS);  // |error of L / |L||: (|error of P| + eps (|l| + t)) / |L|, + its own rounding
+                s.ratio = dot3(s.N, L) * s.invl;               // N.L: one multiply instead of three for the unit vector
                 // lane masks: lanes still needing a verdict / inside a bound / blocked in float32
                 s.open_m = ballot(s.ratio > 0.0f) & s.valid_m;
                 s.maybe_m = 0ull; s.blocked_m = 0ull;
@@ -643,6 +659,37 @@ __global__ void __launch_bounds__(PTR_FAST_BLOCK) __attribute__((amdgpu_waves_pe
     // (which lanes store is worked out again here rather than carried in a register through the whole kernel)
     const int row_min = quirk ? 1 : 0;                  // PTR_QUIRK_ROW_SHIFT: row 0 has no destination, the others move up one row
     const unsigned qshift = quirk ? (unsigned)a.width : 0u;
+    // The pixel coordinates are worked out again from the thread index (made opaque: otherwise the compiler keeps the
+    // PPL + 1 registers of the top of the kernel alive to here, and at 4 pixels per lane those are the ones that spill).
+    {
+        unsigned tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int ln = (int)(tid & 63u), wv = (int)(tid >> 6);
+#pragma unroll
+        for (int p = 0; p < PPL; p++) {
+            px[p].x = blockIdx.x * (PTR_FAST_BLOCK / 64 * 8 * PPL) + wv * (8 * PPL) + p * 8 + (ln & 7);
+            px[p].row = blockIdx.y * PTR_TILE_H + (ln >> 3);
+        }
+    }
+    if constexpr (!DBG) {
+        // Nearly every wave: its tile lies wholly inside the band, there is no float32 frame and nothing to queue - one
+        // address per lane, the slots 32 bytes apart, no lane masks.
+        const int x0 = blockIdx.x * (PTR_FAST_BLOCK / 64 * 8 * PPL) + wave * (8 * PPL);
+        bool plain = (x0 + 8 * PPL <= a.width) & (tile_row0 + PTR_TILE_H <= a.scan_height) & (a.out32f == nullptr);
+        if constexpr (QUIRK) plain &= blockIdx.y != 0;
+        if constexpr (HYBRID) {
+            unsigned long long um = 0ull;
+#pragma unroll
+            for (int p = 0; p < PPL; p++) um |= unsure[p].mask;
+            plain &= um == 0ull;
+        }
+        if (plain) {
+            uint32_t* dst = out8 + ((unsigned)__umul24((unsigned)a.width, (unsigned)px[0].row) + (unsigned)px[0].x - qshift);
+#pragma unroll
+            for (int p = 0; p < PPL; p++) dst[8 * p] = packed[p];
+            return;
+        }
+    }
 #pragma unroll
     for (int p = 0; p < PPL; p++) {
         const Pixel& r = px[p];
@@ -698,7 +745,13 @@ static hipError_t launch_camera(const RenderArgs& a, int n_frames, hipStream_t s
 {
     const int tw = PTR_FAST_BLOCK / 64 * 8 * PPL;
     dim3 grid((a.width + tw - 1) / tw, (a.scan_height + PTR_TILE_H - 1) / PTR_TILE_H, n_frames);
-    hipLaunchKernelGGL((render_fast_kernel<MODE, DBG, PPL, GENERAL>), grid, dim3(PTR_FAST_BLOCK), 0, s, a);
+    if constexpr (DBG) {                         // (diagnostics: the reasons come in the unshifted layout whatever the flag says)
+        hipLaunchKernelGGL((render_fast_kernel<MODE, DBG, PPL, GENERAL, false>), grid, dim3(PTR_FAST_BLOCK), 0, s, a);
+    } else if (a.flags & 0x0001u /* PTR_QUIRK_ROW_SHIFT */) {
+        hipLaunchKernelGGL((render_fast_kernel<MODE, DBG, PPL, GENERAL, true>), grid, dim3(PTR_FAST_BLOCK), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((render_fast_kernel<MODE, DBG, PPL, GENERAL, false>), grid, dim3(PTR_FAST_BLOCK), 0, s, a);
+    }
     return hipGetLastError();
 }
 
@@ -708,12 +761,14 @@ static hipError_t launch_variant(const RenderArgs& a, int n_frames, hipStream_t 
     return a.cam.general ? launch_camera<MODE, DBG, PPL, true>(a, n_frames, s) : launch_camera<MODE, DBG, PPL, false>(a, n_frames, s);
 }
 
+// pixels per lane by mode: the tolerant form carries fewer values per pixel and takes a wider tile at one wave per SIMD less
+int fast_kernel_ppl(int mode) { return mode == 2 ? PTR_FAST_PPL_TOL : PTR_FAST_PPL; }
 int fast_kernel_rows_per_block() { return PTR_TILE_H; }
-int fast_kernel_cols_per_block() { return PTR_FAST_BLOCK / 64 * 8 * PTR_FAST_PPL; }
+int fast_kernel_cols_per_block(int mode) { return PTR_FAST_BLOCK / 64 * 8 * fast_kernel_ppl(mode); }
 
 hipError_t launch_render_fast(const RenderArgs& a, int n_frames, int mode, hipStream_t s)
 {
-    if (mode == 2) return launch_variant<2, false, PTR_FAST_PPL>(a, n_frames, s);
+    if (mode == 2) return launch_variant<2, false, PTR_FAST_PPL_TOL>(a, n_frames, s);
     if (mode == 1) return launch_variant<1, false, PTR_FAST_PPL>(a, n_frames, s);
     if (a.flags & 0x8000u /* PTR_DEBUG_REASONS */) return launch_variant<0, true, PTR_FAST_PPL>(a, n_frames, s);
     return launch_variant<0, false, PTR_FAST_PPL>(a, n_frames, s);

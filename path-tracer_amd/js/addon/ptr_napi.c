@@ -802,7 +802,7 @@ NAPI_MODULE_INIT()
     napi_value v;
     const struct { const char *name; uint32_t val; } consts[] = {
         {"QUIRK_ROW_SHIFT", PTR_QUIRK_ROW_SHIFT}, {"MODE_EXACT_F64", PTR_MODE_EXACT_F64},
-        {"MODE_F32_ONLY", PTR_MODE_F32_ONLY}, {"FLAG_STATS", PTR_FLAG_STATS}, {"ABI_VERSION", PTR_ABI_VERSION},
+        {"MODE_F32_ONLY", PTR_MODE_F32_ONLY}, {"MODE_TOLERANT", PTR_MODE_TOLERANT}, {"FLAG_STATS", PTR_FLAG_STATS}, {"ABI_VERSION", PTR_ABI_VERSION},
     };
     for (size_t k = 0; k < sizeof consts / sizeof consts[0]; k++) {
         napi_create_uint32(env, consts[k].val, &v);

@@ -8,5 +8,6 @@ export { default as Color } from './src/Color.js';
 export { default as Camera } from './src/Camera.js';
 export { default as RayTracer } from './src/RayTracer.js';
 export { default as RenderPlanner } from './src/RenderPlanner.js';
+export { createRenderWorker } from './src/RenderWorker.js';   // the worker side of the reference's message protocol
 export { default as RenderCache } from './src/RenderCache.js';
 export { default as RenderCacheDriver, RcCamera } from './src/RenderCacheDriver.js';

@@ -18,8 +18,9 @@ import Plane from './Plane.js';
  * cached on add().  The user's backgroundColor object is never modified (the reference clamps it
  * in place as a side effect of returning it from trace(); do not rely on that).
  *
- * options: { device: 0, mode: 'hybrid' | 'exact' | 'f32' }
+ * options: { device: 0, mode: 'hybrid' | 'tolerant' | 'exact' | 'f32' }
  *   hybrid (default): float32 kernel + float64 re-trace of uncertain pixels; bytes equal the reference
+ *   tolerant: the same with only the discontinuous doubts re-traced; every channel within 1/255 of the reference
  *   exact: every pixel in float64, operation for operation
  *   f32: float32 only (max per-channel error 1/255 except on silhouettes / shadow edges)
  *
@@ -38,7 +39,7 @@ export default class RayTracer {
         this._native = native();
         this._device = options.device | 0;
         this._handle = this._native.create(this._device);
-        const modes = { hybrid: 0, exact: this._native.MODE_EXACT_F64, f32: this._native.MODE_F32_ONLY };
+        const modes = { hybrid: 0, tolerant: this._native.MODE_TOLERANT, exact: this._native.MODE_EXACT_F64, f32: this._native.MODE_F32_ONLY };
         const mode = options.mode === undefined ? 'hybrid' : options.mode;
         if (!(mode in modes)) throw new TypeError(`unknown mode ${mode}`);
         this._modeFlags = modes[mode];

@@ -1,3 +1,4 @@
+import { Worker } from 'worker_threads';
 import RayTracer from './RayTracer.js';
 import Scene from './Scene.js';
 import Sphere from './Sphere.js';
@@ -10,6 +11,10 @@ import Vector3 from './Vector3.js';
  * rendered on the GPU (jobs are dealt round-robin over `options.devices`, default [0]); the
  * serialize -> deserialize hop of the worker protocol (Sphere.js:53-83, RenderWorker.js:27-46) is
  * kept so that updateScene() has the same snapshot semantics.
+ *
+ * options.workerThreads = true keeps the reference's shape to the letter instead: `jobCount` Node worker_threads Workers
+ * running ./RenderWorker.js, each with its own addon instance and GPU context, driven by the reference's four messages
+ * (elements / backgroundColor / dimensions / render -> result, RenderPlanner.js:61-109); dispose() closes them.
  *
  * Band maths as in the reference (:75-76): sectionHeight = floor(height / jobCount),
  * sectionStart = index * sectionHeight; rows past jobCount * sectionHeight are never rendered, and
@@ -30,6 +35,13 @@ export default class RenderPlanner {
 
         const devices = options.devices || [0];
         this.workers = [];
+        this.workerThreads = !!options.workerThreads;
+        if (this.workerThreads) {
+            for (let i = 0; i < jobCount; i++)
+                this.workers.push(new Worker(new URL('./RenderWorker.js', import.meta.url),
+                                             { workerData: { device: devices[i % devices.length], mode: options.mode } }));
+            return;
+        }
         for (let i = 0; i < jobCount; i++) {
             // one renderer ("worker") per job, with its private copy of the scene
             const w = { scene: new Scene(), background: new Vector3(0, 0, 0), dims: null };
@@ -58,6 +70,7 @@ export default class RenderPlanner {
     }
 
     prepareWorker(index, worker) {
+        if (this.workerThreads) return this._prepareThread(index, worker);
         RenderPlanner._loadElements(worker, this.serializedElements);
         worker.background.x = this.backgroundColor.x;
         worker.background.y = this.backgroundColor.y;
@@ -67,7 +80,30 @@ export default class RenderPlanner {
         worker.dims = [this.width, this.height, sectionStart, sectionHeight];
     }
 
+    // the reference's prepareWorker, message for message (RenderPlanner.js:61-101)
+    _prepareThread(index, rendererWorker) {
+        rendererWorker.postMessage({ action: 'elements', data: this.serializedElements });
+        rendererWorker.postMessage({ action: 'backgroundColor', data: [this.backgroundColor.x, this.backgroundColor.y, this.backgroundColor.z] });
+        const sectionHeight = Math.floor(this.height / this.jobCount);
+        const sectionStart = Math.floor(index * sectionHeight);
+        rendererWorker.postMessage({ action: 'dimensions', data: [this.width, this.height, sectionStart, sectionHeight] });
+        rendererWorker.removeAllListeners('message');
+        rendererWorker.removeAllListeners('error');
+        rendererWorker.on('message', (m) => {
+            if (m.action == 'result') {
+                this.completedJobs++;
+                if (this.completedJobs == this.jobCount) this.running = false;
+                this.onUpdateReceived(sectionStart, sectionHeight, m.data);
+            } else if (m.action == 'error') {
+                this.running = false;
+                this.onError(new Error(m.data));
+            }
+        });
+        rendererWorker.on('error', (err) => { this.running = false; this.onError(err); });
+    }
+
     startWorker(worker) {
+        if (this.workerThreads) { worker.postMessage({ action: 'render' }); return; }
         const [w, h, sectionStart, sectionHeight] = worker.dims;
         worker.tracer.renderAsync(w, h, sectionStart, sectionHeight).then(buffer => {
             this.completedJobs++;
@@ -86,6 +122,7 @@ export default class RenderPlanner {
      * putImageData.  Uses the scene snapshot of the last initialize() / updateScene().  Returns an ArrayBuffer.
      */
     renderFrameGathered(options = {}) {
+        if (this.workerThreads) throw new Error('renderFrameGathered needs the in-process renderers (workerThreads: false)');
         const first = [];
         const seen = new Set();
         for (const w of this.workers) {              // one renderer per distinct GPU, in device order of appearance
@@ -105,8 +142,15 @@ export default class RenderPlanner {
 
     updateScene() {
         this.serializeScene();
+        if (this.workerThreads) {
+            for (const w of this.workers) w.postMessage({ action: 'elements', data: this.serializedElements });    // RenderPlanner.js:116-128
+            return;
+        }
         for (const w of this.workers) RenderPlanner._loadElements(w, this.serializedElements);
     }
 
-    dispose() { for (const w of this.workers) w.tracer.dispose(); }
+    dispose() {
+        if (this.workerThreads) { for (const w of this.workers) w.postMessage({ action: 'close' }); return; }
+        for (const w of this.workers) w.tracer.dispose();
+    }
 }

@@ -6,7 +6,8 @@ import fs from 'fs';
 import path from 'path';
 import { fileURLToPath } from 'url';
 import assert from 'assert';
-import { Plane, Vector3, Material, Sphere, Scene, Color, Camera, RayTracer, RenderPlanner, RenderCache, RenderCacheDriver, RcCamera } from '../index.js';
+import { Worker } from 'worker_threads';
+import { Plane, Vector3, Material, Sphere, Scene, Color, Camera, RayTracer, RenderPlanner, RenderCache, RenderCacheDriver, RcCamera, createRenderWorker } from '../index.js';
 
 const here = path.dirname(fileURLToPath(import.meta.url));
 const golden = path.join(here, '..', '..', '..', 'tests', 'golden');
@@ -105,6 +106,23 @@ function cpuTests() {
         if (process.env.PTR_EXPECT_GPU) return;
         assert.ok(threw, 'expected an error without a GPU');
         assert.ok(/no CPU fallback/.test(threw.message), threw.message);
+    });
+    test('worker protocol handler: scene, background and dimensions messages build the worker\'s state; render reports errors', () => {
+        const posted = [];
+        const onMessage = createRenderWorker((msg) => posted.push(msg), { device: 0 });
+        const elements = buildExample1().getElements().map(el => el.serialize());
+        onMessage({ action: 'elements', data: elements });
+        onMessage({ data: { action: 'backgroundColor', data: [2, 2, 2] } });          // the DOM event shape is taken too
+        onMessage({ action: 'dimensions', data: [320, 240, 30, 30] });
+        onMessage({ action: 'elements', data: elements.slice(0, 3) });                 // replaces, does not append (RenderWorker.js:28)
+        assert.strictEqual(posted.length, 0);
+        if (!process.env.PTR_EXPECT_GPU) {
+            onMessage({ action: 'render' });                                            // no GPU here: an error message, not a throw, not a hang
+            assert.strictEqual(posted.length, 1);
+            assert.strictEqual(posted[0].action, 'error');
+            assert.ok(/no CPU fallback|HIP|device/i.test(posted[0].data));
+        }
+        onMessage({ action: 'close' });
     });
 }
 
@@ -445,6 +463,75 @@ async function gpuTests() {
         second.sort((a, b) => a.start - b.start);
         assert.ok(sameBytes(Buffer.from(second[3].buf8), new Uint8Array(ref.render(320, 240, 90, 30))));
         ref.dispose(); planner.dispose();
+    });
+    await atest('worker protocol: 2 worker_threads Workers, each with its own addon instance, render the 8 bands through messages', async () => {
+        // raytracer-js-master/src/RenderWorker.js:23-70 driven by hand, the way a caller with workers of its own would:
+        // elements / backgroundColor / dimensions / render -> result; bytes = the unmodified reference's 8 bands
+        const m = index.bands['example1@320x240/8'];
+        const want = u8(m.file);
+        const elements = buildExample1().getElements().map(el => el.serialize());
+        const url = new URL('../src/RenderWorker.js', import.meta.url);
+        const workers = [0, 1].map(() => new Worker(url, { workerData: { device: 0 } }));
+        const band = Math.floor(m.height / m.jobs);
+        const got = Buffer.alloc(want.length);
+        await Promise.all(workers.map((w, k) => new Promise((resolve, reject) => {
+            const mine = [];
+            for (let j = k; j < m.jobs; j += 2) mine.push(j);          // worker k takes bands k, k + 2, ...
+            let at = 0;
+            const next = () => {
+                w.postMessage({ action: 'dimensions', data: [m.width, m.height, mine[at] * band, band] });
+                w.postMessage({ action: 'render' });
+            };
+            w.on('error', reject);
+            w.on('message', (msg) => {
+                if (msg.action == 'error') return reject(new Error(msg.data));
+                assert.strictEqual(msg.action, 'result');
+                assert.ok(msg.data instanceof Uint8ClampedArray && msg.data.length == m.width * band * 4);
+                Buffer.from(msg.data.buffer).copy(got, mine[at] * band * m.width * 4);
+                if (++at < mine.length) next(); else { w.postMessage({ action: 'close' }); resolve(); }
+            });
+            w.postMessage({ action: 'elements', data: elements });
+            w.postMessage({ action: 'backgroundColor', data: [2, 2, 2] });
+            next();
+        })));
+        assert.ok(sameBytes(got, want));
+        await Promise.all(workers.map(w => new Promise(resolve => w.once('exit', resolve))));     // 'close' ends the threads
+    });
+    await atest('RenderPlanner {workerThreads: true}: the reference\'s planner over real Workers, bytes equal the reference bands', async () => {
+        const m = index.bands['example1@320x240/8'];
+        const scene = buildExample1();
+        const planner = new RenderPlanner(m.jobs, scene, new Vector3(2, 2, 2), m.width, m.height, { workerThreads: true });
+        const run = () => new Promise((resolve, reject) => {
+            const pieces = [];
+            planner.onError = reject;
+            planner.onUpdateReceived = (start, height, buf8) => { pieces.push({ start, buf8 }); if (!planner.isRunning()) resolve(pieces); };
+            planner.start();
+        });
+        planner.initialize();
+        const pieces = await run();
+        assert.strictEqual(pieces.length, m.jobs);
+        pieces.sort((a, b) => a.start - b.start);
+        assert.ok(sameBytes(Buffer.concat(pieces.map(p => Buffer.from(p.buf8))), u8(m.file)));
+        scene.getElements()[1].center = new Vector3(0, 3, -20);
+        planner.updateScene();                                          // a new snapshot goes to every worker
+        scene.getElements()[1].center = new Vector3(0, -3, -20);
+        const second = await run();
+        const ref = new RayTracer(new Vector3(2, 2, 2), (() => { const s = buildExample1(); s.getElements()[1].center = new Vector3(0, 3, -20); return s; })());
+        second.sort((a, b) => a.start - b.start);
+        assert.ok(sameBytes(Buffer.from(second[3].buf8), new Uint8Array(ref.render(320, 240, 90, 30))));
+        ref.dispose();
+        const exits = planner.workers.map(w => new Promise(resolve => w.once('exit', resolve)));
+        planner.dispose();
+        await Promise.all(exits);
+    });
+    test('mode tolerant: every channel within 1 of the reference frame', () => {
+        const m = index.frames['example1@160x120'];
+        const rt = new RayTracer(new Vector3(2, 2, 2), buildExample1(), undefined, { mode: 'tolerant' });
+        const got = new Uint8Array(rt.render(m.width, m.height)), want = u8(m.file);
+        let worst = 0;
+        for (let k = 0; k < want.length; k++) worst = Math.max(worst, Math.abs(got[k] - want[k]));
+        assert.ok(worst <= 1);
+        rt.dispose();
     });
     await atest('dispose() right after renderAsync(): the job in flight finishes on a live context', async () => {
         const m = index.frames['example1@160x120'];

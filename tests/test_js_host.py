@@ -28,7 +28,7 @@ def test_js_host_logic_cpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present: covered by the gpu test")
     out = _run("cpu")
-    assert "7 JS tests passed" in out
+    assert "8 JS tests passed" in out
 
 
 @pytest.mark.gpu
