@@ -251,6 +251,22 @@ int ptr_render_strips_device(ptr_ctx *ctx, const ptr_params *p, const ptr_strips
  *   one process, several GPUs (the Node host): ptr_comm_init_all on the array of contexts (rank = index).
  * n_ranks == 1 is allowed (nothing is sent).  ptr_destroy ends a context's membership; ptr_comm_destroy does so early. */
 #define PTR_COMM_ID_BYTES 128
+#define PTR_COMM_MAX_RANKS 64      /* ranks of one communicator (ptr_comm_init_rank / _all, ptr_gather_strips_all, ptr_render_multi) */
+/* Sizes of one gather, as ptr_gather_strips_device / _all work them out (pure host arithmetic, no GPU, no context): for a
+ * host that allocates the buffers, and for checking the 64-bit arithmetic at sizes no test box holds (8 ranks x 2 048
+ * frames).  Replaces nothing in the reference (its bands are separate Uint8ClampedArrays, RenderPlanner.js:85-100).       */
+typedef struct ptr_gather_sizes {
+    int32_t  rows_max;          /* rows of the largest part (part 0): every rank's buffer holds this many per frame       */
+    int32_t  rows;              /* rows of this part                                                                      */
+    uint64_t frame_stride_px;   /* pixels between two frames of a rank's compact buffer                                   */
+    uint64_t count;             /* pixels a rank sends = frame_stride_px * n_frames (the ncclSend / ncclRecv count)       */
+    uint64_t local_bytes;       /* bytes of a rank's compact buffer                                                       */
+    uint64_t root_stage_bytes;  /* bytes of the root's staging buffer: (n_parts - 1) * local_bytes                        */
+    uint64_t full_bytes;        /* bytes of the whole frames on the root                                                  */
+    uint64_t last_full_index;   /* pixel index, in the whole frames, of this part's last pixel of the last frame          */
+} ptr_gather_sizes;
+int ptr_gather_plan(int width, int height, int strip_height, int n_frames, uint64_t frame_stride_px, int part, int n_parts,
+                    ptr_gather_sizes *out);
 int ptr_comm_unique_id(unsigned char id[PTR_COMM_ID_BYTES]);
 int ptr_comm_init_rank(ptr_ctx *ctx, const unsigned char id[PTR_COMM_ID_BYTES], int rank, int n_ranks);
 int ptr_comm_init_all(ptr_ctx *const *ctxs, int n_ctxs);

@@ -1,120 +1,18 @@
-// ptr_api.hip — host side of the C ABI declared in include/ptr.h.
+// ptr_api.hip — host side of the C ABI declared in include/ptr.h: context, scene, render and trace entry points.
+// (ptr_api_rc.hip: the render cache; ptr_api_comm.hip: RCCL, the strip gather, the multi-GPU forms; ptr_host.h: what they share.)
 //
 // Owns all device memory of a renderer context: the frame blocks (scene sequence flattened to
 // the layouts of ptr_device.h), the re-trace queue and its two counter words, the stats words
 // and staging buffers for the host-pointer entry points.  There is no CPU implementation of
 // the path in here: without a GPU ptr_create fails.
-#include <hip/hip_runtime.h>
-#include <dlfcn.h>
+#include "ptr_host.h"
 
-#include <cmath>
-#include <cstdarg>
-#include <cstddef>
-#include <cstdio>
-#include <cstring>
-#include <mutex>
-#include <new>
-#include <string>
-#include <vector>
-
-#include "../../include/ptr.h"
-#include "ptr_device.h"
-#include "ptr_kernels.h"
-
-using namespace ptr;
-
-namespace {
-
-thread_local char g_create_error[512] = "";      // fixed buffers: reporting an error must never throw
-
-struct DeviceBuffer {
-    void*  ptr = nullptr;
-    size_t bytes = 0;
-};
-
-// The render cache when it lives on the GPU (ptr_rc_cache_*, ptr_rc_next_frame): Driver.cache and Driver.buffer as flat
-// arrays, the words and lists one frame's passes hand to each other, and two pinned host buffers for what crosses PCIe.
-struct RcCache {
-    int width = 0, height = 0, n_items = 0;
-    bool loaded = false;
-    DeviceBuffer item_pixel, item_hit, item_age, item_rgb;                                  // n_items
-    DeviceBuffer pixel_element, pixel_depth, pixel_rgb, pixel_priority, pixel_sample;       // (width + 2) * (height + 2)
-    DeviceBuffer words;                                                                     // RC_WORDS_*
-    DeviceBuffer cand, picks, pick_item, need, rank, dirs, tr_rgb, tr_hit;                  // up to width * height requests
-    DeviceBuffer frames, temp;
-    unsigned char* host_words = nullptr;
-    int32_t* host_picks = nullptr;
-};
-
-// layout of ptr_ctx::words (device): two queue counters on lines of their own, then the stats
-constexpr size_t WORDS_COUNTERS  = (size_t)PTR_MAX_QUEUES * PTR_COUNTER_STRIDE * sizeof(uint32_t);
-constexpr size_t WORDS_COUNTER_A = 0;
-constexpr size_t WORDS_COUNTER_B = WORDS_COUNTERS;
-constexpr size_t WORDS_STATS     = 2 * WORDS_COUNTERS;     // 8 x uint64
-constexpr size_t WORDS_BYTES     = WORDS_STATS + 256;
-
-// ptr_render_device_noalloc: the same words and the re-trace queue, in an array that belongs to the code object instead of
-// coming from hipMalloc.  Every GPU the library runs on holds its own copy (32 MiB) from the moment the library is loaded;
-// all contexts on one GPU share that copy.  Host code never uses the array's name as an address: ptr_create asks for this
-// GPU's address once (hipGetSymbolAddress) and everything below works with that pointer.
-constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t)32 << 20;
-constexpr size_t NOALLOC_QUEUE_OFFSET  = (WORDS_BYTES + 255) / 256 * 256;
+namespace ptrh {
+thread_local char g_create_error[512] = "";
 static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+}  // namespace ptrh
 
-}  // namespace
-
-struct ptr_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::mutex mu;
-    char err[512] = "";
-
-    // host copy of the scene sequence (float64, C-ABI plane order)
-    std::vector<double> soa;
-    int n_spheres = 0;
-    int n_frames = 0;
-    bool have_scene = false;
-    double bg[3] = {0, 0, 0};
-    ptr_camera cam;
-    bool cam_general = false;
-    // extension scene data (ptr_set_extension_f64): planes (14 rows of n_planes), Phong terms (ks, exponent per element)
-    std::vector<double> planes, phong;
-    int n_planes = 0, n_phong = 0;     // n_phong: elements the Phong arrays were given for (0 = none)
-    bool dirty = true;                 // frame blocks need a rebuild + upload
-    bool needs_exact = false;          // some frame holds values the float32 path cannot take
-
-    DeviceBuffer scenes;               // n_frames frame blocks
-    size_t frame_stride = 0;
-    DeviceBuffer queue;                // uint32 per pixel of the largest hybrid call so far
-    DeviceBuffer words;                // see WORDS_*
-    unsigned hybrid_calls = 0;         // picks the counter word of the next hybrid call
-    bool words_dirty = true;           // counters/stats must be zeroed before the next use
-    DeviceBuffer out8, out32f;         // staging for ptr_render
-    DeviceBuffer tr_in_o, tr_in_d, tr_rgb, tr_el, tr_hit, tr_nrm;   // staging for ptr_trace_batch*
-    DeviceBuffer rc_depth, rc_keys, rc_temp;                         // scratch of ptr_rc_reproject*
-    DeviceBuffer rc_hit, rc_age, rc_item, rc_pel, rc_pdep;           // staging for ptr_rc_reproject (host buffers)
-    DeviceBuffer rc_rgb, rc_prgb, rc_pprio, rc_hist, rc_frames;      // staging for ptr_rc_shade (host buffers)
-    DeviceBuffer rc_page;                                            // scratch of ptr_rc_shade*: per-pixel element age
-    RcCache* rcc = nullptr;                                          // ptr_rc_cache_create
-    DeviceBuffer rcm_before, rcm_local_el, rcm_local_dep, rcm_all_el, rcm_all_dep;   // ptr_rc_merge_shards_device / _multi_device
-    std::vector<unsigned char> host_blocks;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // PTR_FLAG_TIMING
-    int timed_kernels = 0;             // kernels bracketed by ev[] in the last timed call
-    // The device-pointer entry points only enqueue, on the caller's stream: last_ev marks the end of the most recent
-    // call's kernels, so that a later call on another stream, a scene upload or ptr_get_stats can order itself behind them.
-    hipEvent_t last_ev = nullptr;
-    hipStream_t last_stream = nullptr;
-    bool have_last = false;
-    // multi-GPU (ptr_comm_*, ptr_gather_strips_*): this context's membership of an RCCL communicator
-    void* comm = nullptr;                   // ncclComm_t
-    int comm_rank = 0, comm_n = 0;          // comm_n 0: no communicator
-    DeviceBuffer gather_stage;              // root: the peers' local buffers as they arrive
-    DeviceBuffer multi_local, multi_full;   // ptr_render_multi: this GPU's part / the whole frame on the root
-    unsigned char* stats_words = nullptr;   // where the last call's kernels put their stats words
-    unsigned char* scratch_dev = nullptr;   // this GPU's address of the static array `scratch`
-};
-
-namespace {
+namespace ptrh {
 
 int fail(ptr_ctx* c, int code, const char* fmt, ...)
 {
@@ -125,15 +23,6 @@ int fail(ptr_ctx* c, int code, const char* fmt, ...)
     return code;
 }
 
-#define HIP_TRY(c, call)                                                                      \
-    do {                                                                                      \
-        hipError_t e_ = (call);                                                               \
-        if (e_ != hipSuccess)                                                                 \
-            return fail((c), PTR_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));     \
-    } while (0)
-
-#define PTR_TRY(expr)                                                                         \
-    do { int rc_ = (expr); if (rc_ != PTR_OK) return rc_; } while (0)
 
 int grow(ptr_ctx* c, DeviceBuffer& b, size_t bytes)
 {
@@ -391,15 +280,27 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
     return needs_exact;
 }
 
+// Is stream s recording a HIP graph?  Then nothing the context keeps may be tied to it: an event recorded on a capturing
+// stream becomes a captured event, and ptr_get_stats' hipEventSynchronize or another stream's wait on it would fail
+// (hipErrorCapturedEvent) or invalidate the capture.  Ordering inside a graph is the graph's own.
+bool stream_is_capturing(hipStream_t s)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st == hipStreamCaptureStatusActive;
+}
+
 // make stream s wait for the kernels of the context's most recent call, if that call went to another stream
 int order_after_last(ptr_ctx* c, hipStream_t s)
 {
+    if (stream_is_capturing(s)) return PTR_OK;      // (the caller orders a graph against earlier work when it launches it)
     if (c->have_last && c->last_stream != s) HIP_TRY(c, hipStreamWaitEvent(s, c->last_ev, 0));
     return PTR_OK;
 }
 
 int mark_launch(ptr_ctx* c, hipStream_t s)
 {
+    if (stream_is_capturing(s)) return PTR_OK;      // nothing was enqueued: the kernels run when the graph is launched
     HIP_TRY(c, hipEventRecord(c->last_ev, s));
     c->last_stream = s;
     c->have_last = true;
@@ -488,22 +389,82 @@ int ensure_words(ptr_ctx* c, hipStream_t s)
     return PTR_OK;
 }
 
+// The float32 error budget of the hit tests (PR_RELB: 10 eps for b = l.d) counts on a camera ray that is good to about one
+// eps, which is what xx R + yy U + F gives while its terms are of the size of the sum: the direction's relative error grows
+// like g = (|xx|max |R| + |yy|max |U| + |F|) / dmin (1.7 for the reference camera at 16:9; measured 1.1 eps there, 3.3 eps at
+// g = 10-11: fov 150 degrees, or aspect 32).  Wide or skewed cameras beyond g = 4 are rendered in float64 rather than trusted
+// to the budget.  dmin = distance of the image plane from the eye.
+bool camera_needs_exact(const ptr_ctx* c, const ptr_params* p, double* dmin_out = nullptr)
+{
+    const double* R = c->cam.right; const double* U = c->cam.up; const double* F = c->cam.forward;
+    const double nx = R[1] * U[2] - R[2] * U[1], ny = R[2] * U[0] - R[0] * U[2], nz = R[0] * U[1] - R[1] * U[0];
+    const double nn = std::sqrt(nx * nx + ny * ny + nz * nz);
+    const double dmin = nn > 0 ? std::fabs(F[0] * nx + F[1] * ny + F[2] * nz) / nn : 0.0;
+    if (dmin_out) *dmin_out = dmin;
+    const double angle = c->cam.tan_half_fov, aspect = (double)p->width / (double)p->height;
+    const double g = dmin > 0 ? (std::fabs(angle * aspect) * std::sqrt(R[0] * R[0] + R[1] * R[1] + R[2] * R[2]) +
+                                 std::fabs(angle) * std::sqrt(U[0] * U[0] + U[1] * U[1] + U[2] * U[2]) +
+                                 std::sqrt(F[0] * F[0] + F[1] * F[1] + F[2] * F[2])) / dmin : 1e300;
+    return !(g <= 4.0);
+}
+
+// Which kernels a call takes, and the re-trace queue a hybrid call needs (ids + 1 or 2 info words per slot).
+struct RenderPlan {
+    bool extension, exact, many, hybrid;
+    uint64_t n_queues, sub_capacity;
+    size_t queue_bytes;
+};
+RenderPlan plan_render(const ptr_ctx* c, const ptr_params* p, int n_frames)
+{
+    RenderPlan r{};
+    const bool stats = (p->flags & PTR_FLAG_STATS) != 0;
+    r.extension = p->max_depth != 0 || p->spp != 1 || c->n_planes > 0 || c->n_phong > 0;
+    // (PTR_MODE_F32_ONLY is the caller's explicit choice of float32 whatever the camera)
+    r.exact = stats || (p->flags & PTR_MODE_EXACT_F64) || c->needs_exact ||
+              (!(p->flags & PTR_MODE_F32_ONLY) && !r.extension && camera_needs_exact(c, p));
+    r.many = c->n_spheres > PTR_FAST_MAX_SPHERES || (p->flags & PTR_DEBUG_FORCE_MANY);
+    r.hybrid = !r.extension && !r.exact && !(p->flags & PTR_MODE_F32_ONLY);
+    if (!r.hybrid) return r;
+    const int rpb = r.many ? many_kernel_rows_per_block() : fast_kernel_rows_per_block();
+    const int cpb = r.many ? PTR_TILE_W : fast_kernel_cols_per_block((p->flags & PTR_MODE_TOLERANT) ? 2 : 1);
+    const uint64_t n_blocks = (uint64_t)((p->width + cpb - 1) / cpb) *
+                              (uint64_t)((p->scan_height + rpb - 1) / rpb) * (uint64_t)n_frames;
+    r.n_queues = 1;                                              // a power of two (the kernel masks)
+    while (r.n_queues * 2 <= PTR_MAX_QUEUES && r.n_queues * 8 <= n_blocks) r.n_queues *= 2;
+    // a workgroup can queue at most its tile's pixels; sub-queue s serves the workgroups b with (b & (n_queues - 1)) == s
+    r.sub_capacity = (n_blocks + r.n_queues - 1) / r.n_queues * (uint64_t)(cpb * rpb);
+    r.queue_bytes = (size_t)(r.n_queues * r.sub_capacity) * (r.many ? 3 : 2) * sizeof(uint32_t);
+    return r;
+}
+
 // Enqueue the kernels of one render call; no synchronisation.  fixed_ws: the kernels' words and re-trace queue come from
 // the static array (ptr_render_device_noalloc) and nothing in here allocates; otherwise from the context's own buffers,
 // grown on demand.
 int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frames,
                    uint32_t* d_out8, float* d_out32f, hipStream_t s,
-                   const ptr_strips* strips = nullptr, uint64_t frame_stride_px = 0, bool fixed_ws = false)
+                   const ptr_strips* strips, uint64_t frame_stride_px, bool fixed_ws)
 {
-    PTR_TRY(order_after_last(c, s));          // queue, counters and stats words are shared by all calls on the context
+    const RenderPlan plan = plan_render(c, p, n_frames);
     if (fixed_ws) {
+        // every reason to refuse the call comes first: a refused call enqueues nothing and leaves the shared array, and
+        // what ptr_get_stats reads, as the last successful call left them
         if (c->dirty)
             return fail(c, PTR_ERR_INVALID, "ptr_render_device_noalloc: the scene is not resident on the GPU yet; call "
                                             "ptr_sync() after the last ptr_set_* call (the upload allocates)");
         if (p->flags & PTR_FLAG_TIMING)
             return fail(c, PTR_ERR_INVALID, "ptr_render_device_noalloc: PTR_FLAG_TIMING is not available (it creates events)");
+        const size_t need = plan.queue_bytes;
+        if (plan.hybrid && need > NOALLOC_SCRATCH_BYTES - NOALLOC_QUEUE_OFFSET)
+            return fail(c, PTR_ERR_INVALID, "ptr_render_device_noalloc: this call needs a re-trace queue of %zu bytes (8 per "
+                                            "pixel of its tiles, 12 with more than 12 spheres), the static array holds %zu: render fewer pixels per call "
+                                            "(about 3.9 M at most), or use ptr_render_device",
+                        need, NOALLOC_SCRATCH_BYTES - NOALLOC_QUEUE_OFFSET);
+    }
+    PTR_TRY(order_after_last(c, s));          // queue, counters and stats words are shared by all calls on the context
+    if (fixed_ws) {
         // every call on this GPU shares the array and finds the last call's contents in it: clear what must start at zero
-        HIP_TRY(c, hipMemsetAsync(c->scratch_dev, 0, WORDS_BYTES, s));
+        // (by a kernel, not hipMemsetAsync: as a HIP graph's memset node the clear came out wrong from the second replay on)
+        HIP_TRY(c, launch_clear_words(c->scratch_dev, WORDS_BYTES, s));
     } else {
         PTR_TRY(ensure_uploaded(c, s));
         PTR_TRY(ensure_words(c, s));
@@ -543,7 +504,6 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
     a.camf.ox = (float)(-a.cam.angle * a.cam.aspect);
     a.camf.sy = (float)(-2.0 * a.cam.inv_h * a.cam.angle);
     a.camf.oy = (float)(a.cam.angle);
-    bool cam_exact = false;
     {
         // Tile culling of the float32 kernel: a wave's pixels are a (8 PPL) x 8 block of the image when its 8 local rows
         // are consecutive image rows.  Unnormalised directions D = xx R + yy U + F differ from the tile centre's by at
@@ -567,26 +527,15 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
         a.ext_cull_on = (rows_consecutive && snx < 0.5) ? 1 : 0;
         a.ext_cull_sin = (float)(snx * (1.0 + 1e-6));
         a.ext_cull_cos = (float)(std::sqrt(std::fmax(0.0, 1.0 - snx * snx)) * (1.0 - 1e-6));
-        // The float32 error budget of the hit tests (PR_RELB: 10 eps for b = l.d) counts on a camera ray that is good to
-        // about one eps, which is what xx R + yy U + F gives while its terms are of the size of the sum: the direction's
-        // relative error grows like g = (|xx|max |R| + |yy|max |U| + |F|) / dmin (1.7 for the reference camera at 16:9;
-        // measured 1.1 eps there, 3.3 eps at g = 10-11: fov 150 degrees, or aspect 32).  Wide or skewed cameras beyond
-        // g = 4 are rendered in float64 rather than trusted to the budget.
-        const double g = dmin > 0 ? (std::fabs(a.cam.angle * a.cam.aspect) * std::sqrt(R[0] * R[0] + R[1] * R[1] + R[2] * R[2]) +
-                                     std::fabs(a.cam.angle) * std::sqrt(U[0] * U[0] + U[1] * U[1] + U[2] * U[2]) +
-                                     std::sqrt(F[0] * F[0] + F[1] * F[1] + F[2] * F[2])) / dmin : 1e300;
-        cam_exact = !(g <= 4.0);
     }
     a.out8 = d_out8;
     a.out32f = d_out32f;
     unsigned char* words = fixed_ws ? c->scratch_dev : static_cast<unsigned char*>(c->words.ptr);
     a.stats = reinterpret_cast<unsigned long long*>(words + WORDS_STATS);
-    c->stats_words = words + WORDS_STATS;
+    c->stats_words = words + WORDS_STATS;       // (no rejection below this line)
 
     const bool stats = (p->flags & PTR_FLAG_STATS) != 0;
-    // (PTR_MODE_F32_ONLY is the caller's explicit choice of float32 whatever the camera)
-    const bool exact = stats || (p->flags & PTR_MODE_EXACT_F64) || c->needs_exact ||
-                       (cam_exact && !(p->flags & PTR_MODE_F32_ONLY) && p->max_depth == 0 && p->spp == 1);
+    const bool exact = plan.exact;
     const bool timing = (p->flags & PTR_FLAG_TIMING) != 0;
     if (stats && !fixed_ws) HIP_TRY(c, hipMemsetAsync(words + WORDS_STATS, 0, 256, s));
     if (timing) {
@@ -596,7 +545,7 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
         HIP_TRY(c, hipEventRecord(c->ev[0], s));
     }
 
-    if (p->max_depth != 0 || p->spp != 1 || c->n_planes > 0 || c->n_phong > 0) {
+    if (plan.extension) {
         // Extension modes (bounces, samples, planes, Phong terms): float64 = the specification bit for bit, and that is the DEFAULT: a float32 ray tree has no
         // error bounds yet that would tell which pixels to re-do (errors grow with every bounce off a curved surface), and
         // the contract is <= 1/255 on every pixel.  PTR_MODE_F32_ONLY asks for the float32 throughput form explicitly.
@@ -610,7 +559,7 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
         if (timing) { HIP_TRY(c, hipEventRecord(c->ev[1], s)); c->timed_kernels = 1; }
         return mark_launch(c, s);
     }
-    const bool many = c->n_spheres > PTR_FAST_MAX_SPHERES || (p->flags & PTR_DEBUG_FORCE_MANY);
+    const bool many = plan.many;
     if (!many && (uint64_t)n_frames * (uint64_t)c->frame_stride >= (1ull << 32))
         return fail(c, PTR_ERR_INVALID, "internal: %d frame blocks of %zu bytes span 4 GB or more", n_frames, c->frame_stride);
     if (p->flags & PTR_MODE_F32_ONLY) {
@@ -619,24 +568,9 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
         return mark_launch(c, s);
     }
     // hybrid: float32 kernel fills the sub-queues, float64 kernel drains them
-    const int rpb = many ? many_kernel_rows_per_block() : fast_kernel_rows_per_block();
-    const int cpb = many ? PTR_TILE_W : fast_kernel_cols_per_block((p->flags & PTR_MODE_TOLERANT) ? 2 : 1);
-    const uint64_t n_blocks = (uint64_t)((p->width + cpb - 1) / cpb) *
-                              (uint64_t)((p->scan_height + rpb - 1) / rpb) * (uint64_t)n_frames;
-    uint64_t n_queues = 1;                                     // a power of two (the kernel masks)
-    while (n_queues * 2 <= PTR_MAX_QUEUES && n_queues * 8 <= n_blocks) n_queues *= 2;
-    // a workgroup can queue at most PTR_BLOCK pixels; sub-queue s serves the workgroups b with (b & (n_queues - 1)) == s
-    const uint64_t sub_capacity = (n_blocks + n_queues - 1) / n_queues * (uint64_t)(cpb * rpb);
-    const size_t queue_bytes = (size_t)(n_queues * sub_capacity) * (many ? 3 : 2) * sizeof(uint32_t);   // ids + 1 or 2 info words
-    if (fixed_ws) {
-        if (queue_bytes > NOALLOC_SCRATCH_BYTES - NOALLOC_QUEUE_OFFSET)
-            return fail(c, PTR_ERR_INVALID, "ptr_render_device_noalloc: this call needs a re-trace queue of %zu bytes (8 per "
-                                            "pixel of its tiles, 12 with more than 12 spheres), the static array holds %zu: render fewer pixels per call "
-                                            "(about 3.9 M at most), or use ptr_render_device",
-                        queue_bytes, NOALLOC_SCRATCH_BYTES - NOALLOC_QUEUE_OFFSET);
-    } else {
-        PTR_TRY(grow(c, c->queue, queue_bytes));
-    }
+    const uint64_t n_queues = plan.n_queues, sub_capacity = plan.sub_capacity;
+    const size_t queue_bytes = plan.queue_bytes;
+    if (!fixed_ws) PTR_TRY(grow(c, c->queue, queue_bytes));       // (the static array's size was checked before anything was enqueued)
     // (the static array was cleared above: its calls always use counter set A)
     const bool odd = !fixed_ws && (c->hybrid_calls & 1u) != 0;
     a.queue = fixed_ws ? reinterpret_cast<uint32_t*>(c->scratch_dev + NOALLOC_QUEUE_OFFSET) : static_cast<uint32_t*>(c->queue.ptr);
@@ -683,7 +617,9 @@ int set_scene_locked(ptr_ctx* c, const double* soa, int n, int n_frames)
     return PTR_OK;
 }
 
-}  // namespace
+}  // namespace ptrh
+
+// =============================================================================================
 
 // =============================================================================================
 extern "C" {
@@ -846,8 +782,11 @@ int ptr_set_extension_f64(ptr_ctx* c, const double* planes_soa, int n_planes, co
             return fail(c, PTR_ERR_INVALID, "element %d: ks must be >= 0 and the exponent an integer in 1..65536 (got %g, %g)", k, ks, m);
     }
     try {
-        c->planes.assign(planes_soa, planes_soa + (size_t)14 * (size_t)n_planes);
-        if (phong) c->phong.assign(phong, phong + 2 * (size_t)n_elements); else c->phong.clear();
+        // both lists are built aside and swapped in together with their counts: a failed allocation leaves the context as it was
+        std::vector<double> new_planes(planes_soa, planes_soa + (size_t)14 * (size_t)n_planes), new_phong;
+        if (phong) new_phong.assign(phong, phong + 2 * (size_t)n_elements);
+        c->planes.swap(new_planes);
+        c->phong.swap(new_phong);
     } catch (const std::bad_alloc&) {
         return fail(c, PTR_ERR_INVALID, "out of host memory");
     }
@@ -1064,529 +1003,6 @@ int ptr_trace_batch(ptr_ctx* c, const float* dirs_xyz, int n,
     return PTR_OK;
 }
 
-namespace {
-int rc_check(ptr_ctx* c, const ptr_rc_camera* cam, int n_items, const void* hit, const void* age, const void* item_pixel,
-             const void* pel, const void* pdep)
-{
-    if (!cam) return fail(c, PTR_ERR_INVALID, "camera is NULL");
-    if (cam->width < 1 || cam->height < 1 || (long long)(cam->width + 2) * (cam->height + 2) >= (1ll << 31))
-        return fail(c, PTR_ERR_INVALID, "bad frame size %d x %d", cam->width, cam->height);
-    if (n_items < 0) return fail(c, PTR_ERR_INVALID, "n_items < 0");
-    if (!pel || !pdep || (n_items > 0 && (!hit || !age || !item_pixel)))
-        return fail(c, PTR_ERR_INVALID, "a required buffer is NULL");
-    return PTR_OK;
-}
-
-// enqueue the pass on stream s; all data pointers are device memory.  Caller holds c->mu.
-int rc_enqueue(ptr_ctx* c, const ptr_rc_camera* cam, int n_items, const double* d_hit, double* d_age, double age_factor,
-               double depth_threshold, int32_t* d_item_pixel, int32_t* d_pel, double* d_pdep, hipStream_t s, int item_base = 0,
-               uint8_t* d_pixel_sample = nullptr)      // (the frame loop's sample flags: cleared with the grid's interior)
-{
-    const size_t n = (size_t)(n_items > 0 ? n_items : 1);
-    PTR_TRY(grow(c, c->rc_depth, n * sizeof(double)));
-    PTR_TRY(grow(c, c->rc_keys, 4 * n * sizeof(uint32_t)));
-    const size_t temp = rc_sort_temp_bytes(n_items > 0 ? n_items : 1, cam->width, cam->height);
-    PTR_TRY(grow(c, c->rc_temp, temp > 0 ? temp : 16));
-    RcArgs a;
-    std::memset(&a, 0, sizeof a);
-    std::memcpy(a.from, cam->from, sizeof a.from);
-    std::memcpy(a.view, cam->view, sizeof a.view);
-    std::memcpy(a.proj, cam->proj, sizeof a.proj);
-    a.width = cam->width; a.height = cam->height; a.n_items = n_items; a.item_base = item_base;
-    a.age_factor = age_factor; a.depth_threshold = depth_threshold;
-    a.hit_xyz = d_hit; a.age = d_age; a.item_pixel = d_item_pixel; a.pixel_element = d_pel; a.pixel_depth = d_pdep;
-    a.pixel_sample = d_pixel_sample;
-    a.item_depth = static_cast<double*>(c->rc_depth.ptr);
-    uint32_t* k = static_cast<uint32_t*>(c->rc_keys.ptr);
-    a.sort_key = k; a.sort_val = k + n; a.sorted_key = k + 2 * n; a.sorted_val = k + 3 * n;
-    HIP_TRY(c, launch_rc_reproject(a, c->rc_temp.ptr, c->rc_temp.bytes, s));
-    return PTR_OK;
-}
-}  // namespace
-
-namespace {
-int rc_shade_check(ptr_ctx* c, const ptr_rc_shade_params* p, int n_items, const void* pel, const void* pdep, const void* age,
-                   const void* rgb, const void* prgb, const void* pprio, const void* hist, const void* totals)
-{
-    if (!p) return fail(c, PTR_ERR_INVALID, "params is NULL");
-    if (p->width < 1 || p->height < 1 || (long long)(p->width + 2) * (p->height + 2) >= (1ll << 31))
-        return fail(c, PTR_ERR_INVALID, "bad frame size %d x %d", p->width, p->height);
-    if (n_items < 0) return fail(c, PTR_ERR_INVALID, "n_items < 0");
-    if (!pel || !pdep || !prgb || !pprio || !hist || !totals || (n_items > 0 && (!age || !rgb)))
-        return fail(c, PTR_ERR_INVALID, "a required buffer is NULL");
-    return PTR_OK;
-}
-
-RcShadeArgs rc_shade_args(const ptr_rc_shade_params* p, int n_items)
-{
-    RcShadeArgs a;
-    std::memset(&a, 0, sizeof a);
-    a.width = p->width; a.height = p->height; a.n_items = n_items;
-    a.age_factor = p->age_factor; a.interpolation_zero = p->interpolation_zero;
-    a.interpolation_random = p->interpolation_random; a.priority_max = p->priority_max;
-    return a;
-}
-}  // namespace
-
-int ptr_rc_shade_device(ptr_ctx* c, const ptr_rc_shade_params* p, int n_items, const void* d_pixel_element,
-                        const void* d_pixel_depth, void* d_item_age, const void* d_item_rgb, void* d_pixel_rgb,
-                        void* d_pixel_priority, void* d_hist, void* d_totals, void* d_color_frame,
-                        void* d_reprojection_frame, void* d_priority_frame, void* stream)
-{
-    if (!c) return PTR_ERR_INVALID;
-    std::lock_guard<std::mutex> g(c->mu);
-    PTR_TRY(rc_shade_check(c, p, n_items, d_pixel_element, d_pixel_depth, d_item_age, d_item_rgb, d_pixel_rgb, d_pixel_priority,
-                           d_hist, d_totals));
-    HIP_TRY(c, hipSetDevice(c->device));
-    RcShadeArgs a = rc_shade_args(p, n_items);
-    a.pixel_element = static_cast<const int32_t*>(d_pixel_element); a.pixel_depth = static_cast<const double*>(d_pixel_depth);
-    a.item_age = static_cast<double*>(d_item_age); a.item_rgb = static_cast<const uint32_t*>(d_item_rgb);
-    a.pixel_rgb = static_cast<uint32_t*>(d_pixel_rgb); a.pixel_priority = static_cast<int32_t*>(d_pixel_priority);
-    a.hist = static_cast<uint32_t*>(d_hist); a.totals = static_cast<long long*>(d_totals);
-    a.color_frame = static_cast<uint32_t*>(d_color_frame); a.reprojection_frame = static_cast<uint32_t*>(d_reprojection_frame);
-    a.priority_frame = static_cast<uint32_t*>(d_priority_frame);
-    PTR_TRY(grow(c, c->rc_page, (size_t)(p->width + 2) * (size_t)(p->height + 2) * sizeof(double)));
-    a.pixel_age = static_cast<double*>(c->rc_page.ptr);
-    HIP_TRY(c, launch_rc_shade(a, stream ? static_cast<hipStream_t>(stream) : c->stream));
-    return PTR_OK;
-}
-
-int ptr_rc_shade(ptr_ctx* c, const ptr_rc_shade_params* p, int n_items, const int32_t* pixel_element, const double* pixel_depth,
-                 double* item_age, const uint32_t* item_rgb, uint32_t* pixel_rgb, int32_t* pixel_priority, uint32_t* hist,
-                 double stats[3], uint32_t* color_frame, uint32_t* reprojection_frame, uint32_t* priority_frame)
-{
-    if (!c) return PTR_ERR_INVALID;
-    std::lock_guard<std::mutex> g(c->mu);
-    PTR_TRY(rc_shade_check(c, p, n_items, pixel_element, pixel_depth, item_age, item_rgb, pixel_rgb, pixel_priority, hist, stats));
-    HIP_TRY(c, hipSetDevice(c->device));
-    const size_t n = (size_t)n_items, cells = (size_t)(p->width + 2) * (size_t)(p->height + 2), px = (size_t)p->width * (size_t)p->height;
-    PTR_TRY(grow(c, c->rc_pel, cells * sizeof(int32_t)));
-    PTR_TRY(grow(c, c->rc_pdep, cells * sizeof(double)));
-    PTR_TRY(grow(c, c->rc_age, (n ? n : 1) * sizeof(double)));
-    PTR_TRY(grow(c, c->rc_rgb, (n ? n : 1) * sizeof(uint32_t)));
-    PTR_TRY(grow(c, c->rc_prgb, cells * sizeof(uint32_t)));
-    PTR_TRY(grow(c, c->rc_pprio, cells * sizeof(int32_t)));
-    PTR_TRY(grow(c, c->rc_hist, 3 * 256 * sizeof(uint32_t) + 3 * sizeof(long long)));
-    PTR_TRY(grow(c, c->rc_frames, 3 * px * sizeof(uint32_t)));
-    hipStream_t s = c->stream;
-    HIP_TRY(c, hipMemcpyAsync(c->rc_pel.ptr, pixel_element, cells * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->rc_pdep.ptr, pixel_depth, cells * sizeof(double), hipMemcpyHostToDevice, s));
-    // grid borders are not written by the pass: they go up and come back as the caller has them
-    HIP_TRY(c, hipMemcpyAsync(c->rc_prgb.ptr, pixel_rgb, cells * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->rc_pprio.ptr, pixel_priority, cells * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    if (n) {
-        HIP_TRY(c, hipMemcpyAsync(c->rc_age.ptr, item_age, n * sizeof(double), hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemcpyAsync(c->rc_rgb.ptr, item_rgb, n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    }
-    RcShadeArgs a = rc_shade_args(p, n_items);
-    a.pixel_element = static_cast<const int32_t*>(c->rc_pel.ptr); a.pixel_depth = static_cast<const double*>(c->rc_pdep.ptr);
-    a.item_age = static_cast<double*>(c->rc_age.ptr); a.item_rgb = static_cast<const uint32_t*>(c->rc_rgb.ptr);
-    a.pixel_rgb = static_cast<uint32_t*>(c->rc_prgb.ptr); a.pixel_priority = static_cast<int32_t*>(c->rc_pprio.ptr);
-    a.hist = static_cast<uint32_t*>(c->rc_hist.ptr);
-    a.totals = reinterpret_cast<long long*>(static_cast<unsigned char*>(c->rc_hist.ptr) + 3 * 256 * sizeof(uint32_t));
-    uint32_t* fr = static_cast<uint32_t*>(c->rc_frames.ptr);
-    a.color_frame = color_frame ? fr : nullptr;
-    a.reprojection_frame = reprojection_frame ? fr + px : nullptr;
-    a.priority_frame = priority_frame ? fr + 2 * px : nullptr;
-    PTR_TRY(grow(c, c->rc_page, cells * sizeof(double)));
-    a.pixel_age = static_cast<double*>(c->rc_page.ptr);
-    HIP_TRY(c, launch_rc_shade(a, s));
-    long long totals[3];
-    if (n) HIP_TRY(c, hipMemcpyAsync(item_age, c->rc_age.ptr, n * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(pixel_rgb, c->rc_prgb.ptr, cells * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(pixel_priority, c->rc_pprio.ptr, cells * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(hist, a.hist, 3 * 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(totals, a.totals, sizeof totals, hipMemcpyDeviceToHost, s));
-    if (color_frame) HIP_TRY(c, hipMemcpyAsync(color_frame, fr, px * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    if (reprojection_frame) HIP_TRY(c, hipMemcpyAsync(reprojection_frame, fr + px, px * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    if (priority_frame) HIP_TRY(c, hipMemcpyAsync(priority_frame, fr + 2 * px, px * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    stats[0] = 100.0 * ((double)totals[0] / ((double)p->width * (double)p->height));     // Driver.js:676
-    stats[1] = (double)totals[1];
-    stats[2] = (double)totals[2];
-    return PTR_OK;
-}
-
-int ptr_rc_reproject_device(ptr_ctx* c, const ptr_rc_camera* cam, int n_items, const void* d_hit_xyz, void* d_age,
-                            double age_factor, double depth_threshold, void* d_item_pixel, void* d_pixel_element,
-                            void* d_pixel_depth, void* stream)
-{
-    if (!c) return PTR_ERR_INVALID;
-    std::lock_guard<std::mutex> g(c->mu);
-    PTR_TRY(rc_check(c, cam, n_items, d_hit_xyz, d_age, d_item_pixel, d_pixel_element, d_pixel_depth));
-    HIP_TRY(c, hipSetDevice(c->device));
-    return rc_enqueue(c, cam, n_items, static_cast<const double*>(d_hit_xyz), static_cast<double*>(d_age), age_factor,
-                      depth_threshold, static_cast<int32_t*>(d_item_pixel), static_cast<int32_t*>(d_pixel_element),
-                      static_cast<double*>(d_pixel_depth), stream ? static_cast<hipStream_t>(stream) : c->stream);
-}
-
-int ptr_rc_reproject(ptr_ctx* c, const ptr_rc_camera* cam, int n_items, const double* hit_xyz, double* age,
-                     double age_factor, double depth_threshold, int32_t* item_pixel, int32_t* pixel_element, double* pixel_depth)
-{
-    if (!c) return PTR_ERR_INVALID;
-    std::lock_guard<std::mutex> g(c->mu);
-    PTR_TRY(rc_check(c, cam, n_items, hit_xyz, age, item_pixel, pixel_element, pixel_depth));
-    HIP_TRY(c, hipSetDevice(c->device));
-    const size_t n = (size_t)n_items, cells = (size_t)(cam->width + 2) * (size_t)(cam->height + 2);
-    PTR_TRY(grow(c, c->rc_hit, (n ? n : 1) * 3 * sizeof(double)));
-    PTR_TRY(grow(c, c->rc_age, (n ? n : 1) * sizeof(double)));
-    PTR_TRY(grow(c, c->rc_item, (n ? n : 1) * sizeof(int32_t)));
-    PTR_TRY(grow(c, c->rc_pel, cells * sizeof(int32_t)));
-    PTR_TRY(grow(c, c->rc_pdep, cells * sizeof(double)));
-    hipStream_t s = c->stream;
-    if (n) {
-        HIP_TRY(c, hipMemcpyAsync(c->rc_hit.ptr, hit_xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemcpyAsync(c->rc_age.ptr, age, n * sizeof(double), hipMemcpyHostToDevice, s));
-    }
-    // the border of the padded grid is not touched by the pass: it goes up and comes back as the caller has it
-    HIP_TRY(c, hipMemcpyAsync(c->rc_pel.ptr, pixel_element, cells * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->rc_pdep.ptr, pixel_depth, cells * sizeof(double), hipMemcpyHostToDevice, s));
-    PTR_TRY(rc_enqueue(c, cam, n_items, static_cast<const double*>(c->rc_hit.ptr), static_cast<double*>(c->rc_age.ptr),
-                       age_factor, depth_threshold, static_cast<int32_t*>(c->rc_item.ptr),
-                       static_cast<int32_t*>(c->rc_pel.ptr), static_cast<double*>(c->rc_pdep.ptr), s));
-    if (n) {
-        HIP_TRY(c, hipMemcpyAsync(age, c->rc_age.ptr, n * sizeof(double), hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipMemcpyAsync(item_pixel, c->rc_item.ptr, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    }
-    HIP_TRY(c, hipMemcpyAsync(pixel_element, c->rc_pel.ptr, cells * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(pixel_depth, c->rc_pdep.ptr, cells * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    return PTR_OK;
-}
-
-// ---- render cache: the frame loop on a resident cache ------------------------------------------------------------
-namespace {
-int rc_cache_ready(ptr_ctx* c, bool need_state)
-{
-    if (!c->rcc) return fail(c, PTR_ERR_INVALID, "no render cache on this context (ptr_rc_cache_create)");
-    if (need_state && !c->rcc->loaded) return fail(c, PTR_ERR_INVALID, "the render cache has no state yet (ptr_rc_cache_upload)");
-    return PTR_OK;
-}
-
-// Driver.directSamples' pick loop (Driver.js:795-822) as pieces of RcPickSegments.  n_cand >= 1, rf > 0.  Returns false when
-// the table would overflow (the caller then adds the sum up step by step).  *n_picks = how many candidates are requested.
-bool rc_pick_segments(double rf, int n_cand, RcPickSegments* g, long long* n_picks)
-{
-    g->n = 0; g->pad = 0;
-    auto push = [&](long long k, long long S, long long D, int e) {
-        if (g->n >= 96 || k > 0x7fffffffll) return false;
-        g->k0[g->n] = (int32_t)k; g->S0[g->n] = S; g->D[g->n] = D; g->e[g->n] = e;
-        g->n++;
-        return true;
-    };
-    if (rf <= 1) {                  // the rounded sum moves by 0 or 1 per step: every candidate is requested, once
-        *n_picks = n_cand;
-        return push(0, 0, 1, 0);
-    }
-    const double C = (double)n_cand;
-    if (!push(0, 0, 0, 0)) return false;                // step 0: the sum is 0
-    long long k = 1;
-    double s = rf, last = 0;                            // 0 + rf is exact
-    while (s < C) {
-        int ex;
-        (void)std::frexp(s, &ex);                       // 2^(ex-1) <= s < 2^ex: one unit in the last place is 2^(ex-53)
-        const int e = ex - 53;
-        const double top = std::ldexp(1.0, ex);
-        const long long S = (long long)std::ldexp(s, -e);
-        const double s1 = s + rf, s2 = s1 + rf;
-        long long D = 0, cnt = 1;
-        // a constant step while the sum stays below `top` (a tie of the rounding may take one step to settle: checked on two)
-        if (s1 < top && (s2 >= top || std::ldexp(s2 - s1, -e) == std::ldexp(s1 - s, -e))) {
-            D = (long long)std::ldexp(s1 - s, -e);
-            const long long L = (long long)std::ceil(std::ldexp(top < C ? top : C, -e));
-            cnt = (L - S + D - 1) / D;
-        }
-        if (!push(k, S, D, e)) return false;
-        k += cnt;
-        last = std::ldexp((double)(S + (cnt - 1) * D), e);
-        s = last + rf;
-    }
-    *n_picks = js_round(last) < C ? k : k - 1;          // `if (i < candidates.length)` can only fail for the last step
-    return true;
-}
-
-int32_t rc_pick_at(const RcPickSegments& g, long long k)       // what rc_pick_index_kernel computes for step k
-{
-    int seg = 0;
-    while (seg + 1 < g.n && k >= g.k0[seg + 1]) seg++;
-    return (int32_t)js_round(std::ldexp((double)(g.S0[seg] + (k - g.k0[seg]) * g.D[seg]), g.e[seg]));
-}
-
-RcLoopArgs rc_loop_args(const RcCache& r)
-{
-    RcLoopArgs a;
-    std::memset(&a, 0, sizeof a);
-    a.width = r.width; a.height = r.height; a.n_items = r.n_items;
-    a.pages = r.n_items / 8;
-    a.item_pixel = static_cast<int32_t*>(r.item_pixel.ptr); a.item_hit = static_cast<double*>(r.item_hit.ptr);
-    a.item_age = static_cast<double*>(r.item_age.ptr); a.item_rgb = static_cast<uint32_t*>(r.item_rgb.ptr);
-    a.pixel_element = static_cast<int32_t*>(r.pixel_element.ptr); a.pixel_rgb = static_cast<uint32_t*>(r.pixel_rgb.ptr);
-    a.pixel_priority = static_cast<int32_t*>(r.pixel_priority.ptr); a.pixel_sample = static_cast<uint8_t*>(r.pixel_sample.ptr);
-    unsigned char* w = static_cast<unsigned char*>(r.words.ptr);
-    a.hist = reinterpret_cast<const uint32_t*>(w + RC_WORDS_HIST);
-    a.words = reinterpret_cast<RcLoopWords*>(w + RC_WORDS_LOOP);
-    a.cand = static_cast<int32_t*>(r.cand.ptr); a.pick_index = static_cast<int32_t*>(r.picks.ptr);
-    a.pick_item = static_cast<int32_t*>(r.pick_item.ptr); a.need = static_cast<int32_t*>(r.need.ptr); a.rank = static_cast<int32_t*>(r.rank.ptr);
-    a.dirs = static_cast<double*>(r.dirs.ptr); a.tr_rgb = static_cast<const double*>(r.tr_rgb.ptr); a.tr_hit = static_cast<const double*>(r.tr_hit.ptr);
-    return a;
-}
-}  // namespace
-
-int ptr_rc_cache_create(ptr_ctx* c, int width, int height, int n_items)
-{
-    if (!c) return PTR_ERR_INVALID;
-    std::lock_guard<std::mutex> g(c->mu);
-    if (width < 1 || height < 1 || (long long)(width + 2) * (height + 2) >= (1ll << 31))
-        return fail(c, PTR_ERR_INVALID, "bad frame size %d x %d", width, height);
-    if (n_items < 8) return fail(c, PTR_ERR_INVALID, "a render cache needs at least one page of 8 items (n_items = %d)", n_items);
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    rc_cache_free(c);
-    RcCache* r = new (std::nothrow) RcCache();
-    if (!r) return fail(c, PTR_ERR_INVALID, "out of host memory");
-    c->rcc = r;
-    r->width = width; r->height = height; r->n_items = n_items;
-    const size_t n = (size_t)n_items, cells = (size_t)(width + 2) * (size_t)(height + 2), px = (size_t)width * (size_t)height;
-    const size_t temp = rc_loop_temp_bytes(width, height);
-    int rc = PTR_OK;
-    const struct { DeviceBuffer* b; size_t bytes; } want[] = {
-        {&r->item_pixel, n * 4}, {&r->item_hit, n * 24}, {&r->item_age, n * 8}, {&r->item_rgb, n * 4},
-        {&r->pixel_element, cells * 4}, {&r->pixel_depth, cells * 8}, {&r->pixel_rgb, cells * 4}, {&r->pixel_priority, cells * 4},
-        {&r->pixel_sample, cells}, {&r->words, RC_WORDS_BYTES}, {&r->cand, px * 4}, {&r->picks, px * 4}, {&r->pick_item, px * 4},
-        {&r->need, px * 4}, {&r->rank, px * 4}, {&r->dirs, px * 24}, {&r->tr_rgb, px * 24}, {&r->tr_hit, px * 24},
-        {&r->frames, 4 * px * 4}, {&r->temp, temp > 0 ? temp : 16}};
-    for (const auto& w : want)
-        if (rc == PTR_OK) rc = grow(c, *w.b, w.bytes);
-    if (rc == PTR_OK && hipHostMalloc(reinterpret_cast<void**>(&r->host_words), RC_WORDS_BYTES, hipHostMallocDefault) != hipSuccess)
-        rc = fail(c, PTR_ERR_HIP, "hipHostMalloc failed for the render cache's words");
-    if (rc == PTR_OK && hipHostMalloc(reinterpret_cast<void**>(&r->host_picks), px * 4, hipHostMallocDefault) != hipSuccess)
-        rc = fail(c, PTR_ERR_HIP, "hipHostMalloc failed for the render cache's pick list");
-    if (rc == PTR_OK && temp == 0) rc = fail(c, PTR_ERR_HIP, "hipCUB did not report its temporary storage size");
-    if (rc != PTR_OK) { (void)hipGetLastError(); rc_cache_free(c); }
-    return rc;
-}
-
-void ptr_rc_cache_destroy(ptr_ctx* c)
-{
-    if (!c) return;
-    std::lock_guard<std::mutex> g(c->mu);
-    (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    rc_cache_free(c);
-}
-
-int ptr_rc_cache_shape(ptr_ctx* c, int* width, int* height, int* n_items)
-{
-    if (!c) return PTR_ERR_INVALID;
-    std::lock_guard<std::mutex> g(c->mu);
-    PTR_TRY(rc_cache_ready(c, false));
-    if (!width || !height || !n_items) return fail(c, PTR_ERR_INVALID, "output pointer is NULL");
-    *width = c->rcc->width; *height = c->rcc->height; *n_items = c->rcc->n_items;
-    return PTR_OK;
-}
-
-int ptr_rc_cache_upload(ptr_ctx* c, const int32_t* item_pixel, const double* item_hit, const double* item_age, const uint32_t* item_rgb,
-                        const int32_t* pixel_element, const double* pixel_depth, const uint32_t* pixel_rgb, const int32_t* pixel_priority,
-                        const uint8_t* pixel_sample, int64_t cache_pointer)
-{
-    if (!c) return PTR_ERR_INVALID;
-    std::lock_guard<std::mutex> g(c->mu);
-    PTR_TRY(rc_cache_ready(c, false));
-    RcCache& r = *c->rcc;
-    if (!item_pixel || !item_hit || !item_age || !item_rgb || !pixel_element || !pixel_depth || !pixel_rgb || !pixel_priority || !pixel_sample)
-        return fail(c, PTR_ERR_INVALID, "a required buffer is NULL");
-    if (cache_pointer < 0 || cache_pointer % 8 != 0 || cache_pointer > (int64_t)r.n_items)
-        return fail(c, PTR_ERR_INVALID, "cache_pointer must be a multiple of 8 in 0..n_items");
-    const size_t n = (size_t)r.n_items, cells = (size_t)(r.width + 2) * (size_t)(r.height + 2);
-    for (size_t i = 0; i < n; i++)
-        if (item_pixel[i] < -1 || (size_t)(item_pixel[i] + 1) > cells)
-            return fail(c, PTR_ERR_INVALID, "item_pixel[%zu] = %d is not a pixel of the grid", i, item_pixel[i]);
-    for (size_t p = 0; p < cells; p++)
-        if (pixel_element[p] < -1 || (size_t)(pixel_element[p] + 1) > n)
-            return fail(c, PTR_ERR_INVALID, "pixel_element[%zu] = %d is not a cache item", p, pixel_element[p]);
-    HIP_TRY(c, hipSetDevice(c->device));
-    hipStream_t s = c->stream;
-    const struct { void* dst; const void* src; size_t bytes; } up[] = {
-        {r.item_pixel.ptr, item_pixel, n * 4}, {r.item_hit.ptr, item_hit, n * 24}, {r.item_age.ptr, item_age, n * 8},
-        {r.item_rgb.ptr, item_rgb, n * 4}, {r.pixel_element.ptr, pixel_element, cells * 4}, {r.pixel_depth.ptr, pixel_depth, cells * 8},
-        {r.pixel_rgb.ptr, pixel_rgb, cells * 4}, {r.pixel_priority.ptr, pixel_priority, cells * 4}, {r.pixel_sample.ptr, pixel_sample, cells}};
-    for (const auto& u : up) HIP_TRY(c, hipMemcpyAsync(u.dst, u.src, u.bytes, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemsetAsync(r.words.ptr, 0, RC_WORDS_BYTES, s));
-    const int32_t page_next = (int32_t)((cache_pointer / 8) % (int64_t)(r.n_items / 8));
-    HIP_TRY(c, hipMemcpyAsync(static_cast<unsigned char*>(r.words.ptr) + RC_WORDS_LOOP + offsetof(RcLoopWords, page_next), &page_next,
-                              sizeof page_next, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    r.loaded = true;
-    return PTR_OK;
-}
-
-int ptr_rc_cache_download(ptr_ctx* c, int32_t* item_pixel, double* item_hit, double* item_age, uint32_t* item_rgb, int32_t* pixel_element,
-                          double* pixel_depth, uint32_t* pixel_rgb, int32_t* pixel_priority, uint8_t* pixel_sample, int64_t* cache_pointer)
-{
-    if (!c) return PTR_ERR_INVALID;
-    std::lock_guard<std::mutex> g(c->mu);
-    PTR_TRY(rc_cache_ready(c, true));
-    RcCache& r = *c->rcc;
-    if (!item_pixel || !item_hit || !item_age || !item_rgb || !pixel_element || !pixel_depth || !pixel_rgb || !pixel_priority ||
-        !pixel_sample || !cache_pointer)
-        return fail(c, PTR_ERR_INVALID, "a required buffer is NULL");
-    const size_t n = (size_t)r.n_items, cells = (size_t)(r.width + 2) * (size_t)(r.height + 2);
-    HIP_TRY(c, hipSetDevice(c->device));
-    hipStream_t s = c->stream;
-    const struct { void* dst; const void* src; size_t bytes; } down[] = {
-        {item_pixel, r.item_pixel.ptr, n * 4}, {item_hit, r.item_hit.ptr, n * 24}, {item_age, r.item_age.ptr, n * 8},
-        {item_rgb, r.item_rgb.ptr, n * 4}, {pixel_element, r.pixel_element.ptr, cells * 4}, {pixel_depth, r.pixel_depth.ptr, cells * 8},
-        {pixel_rgb, r.pixel_rgb.ptr, cells * 4}, {pixel_priority, r.pixel_priority.ptr, cells * 4}, {pixel_sample, r.pixel_sample.ptr, cells}};
-    for (const auto& d : down) HIP_TRY(c, hipMemcpyAsync(d.dst, d.src, d.bytes, hipMemcpyDeviceToHost, s));
-    int32_t page_next = 0;
-    HIP_TRY(c, hipMemcpyAsync(&page_next, static_cast<unsigned char*>(r.words.ptr) + RC_WORDS_LOOP + offsetof(RcLoopWords, page_next),
-                              sizeof page_next, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    *cache_pointer = (int64_t)page_next * 8;        // (the pointer after the last page and 0 name the same next page)
-    return PTR_OK;
-}
-
-int ptr_rc_next_frame(ptr_ctx* c, const ptr_rc_view* view, const ptr_rc_loop_params* par, ptr_rc_frame_stats* out)
-{
-    if (!c) return PTR_ERR_INVALID;
-    std::lock_guard<std::mutex> g(c->mu);
-    PTR_TRY(rc_cache_ready(c, true));
-    if (!view || !par || !out) return fail(c, PTR_ERR_INVALID, "view / params / out is NULL");
-    if (!c->have_scene) return fail(c, PTR_ERR_NO_SCENE, "no scene uploaded (call ptr_set_scene* first)");
-    if (c->n_planes > 0 || c->n_phong > 0)
-        return fail(c, PTR_ERR_UNSUPPORTED, "the render cache traces with the reference's semantics (spheres, Lambert): clear the planes / "
-                                            "Phong terms (ptr_set_extension_f64(ctx, NULL, 0, NULL, 0)) first");
-    if (!(par->priority_max >= 0 && par->priority_max <= 255) || par->priority_max != std::floor(par->priority_max))
-        return fail(c, PTR_ERR_INVALID, "priority_max must be an integer in 0..255");
-    if (!(par->max_samples_per_frame > 0)) return fail(c, PTR_ERR_INVALID, "max_samples_per_frame must be > 0");
-    RcCache& r = *c->rcc;
-    HIP_TRY(c, hipSetDevice(c->device));
-    hipStream_t s = c->stream;
-    PTR_TRY(order_after_last(c, s));
-    PTR_TRY(ensure_uploaded(c, s));
-    const int w = r.width, h = r.height, st = w + 2;
-
-    // reprojectFrame (with detachFrameFromCache: the interior's sample flags)
-    ptr_rc_camera cam;
-    std::memcpy(cam.from, view->from, sizeof cam.from);
-    std::memcpy(cam.view, view->world_inv, sizeof cam.view);
-    std::memcpy(cam.proj, view->proj, sizeof cam.proj);
-    cam.width = w; cam.height = h;
-    PTR_TRY(rc_enqueue(c, &cam, r.n_items, static_cast<const double*>(r.item_hit.ptr), static_cast<double*>(r.item_age.ptr),
-                       par->age_factor, par->depth_threshold, static_cast<int32_t*>(r.item_pixel.ptr),
-                       static_cast<int32_t*>(r.pixel_element.ptr), static_cast<double*>(r.pixel_depth.ptr), s, 0,
-                       static_cast<uint8_t*>(r.pixel_sample.ptr)));
-
-    // depthCulling + fillGaps
-    ptr_rc_shade_params sp = {w, h, par->age_factor, par->interpolation_zero, par->interpolation_random, par->priority_max};
-    RcShadeArgs sa = rc_shade_args(&sp, r.n_items);
-    unsigned char* words = static_cast<unsigned char*>(r.words.ptr);
-    sa.pixel_element = static_cast<const int32_t*>(r.pixel_element.ptr); sa.pixel_depth = static_cast<const double*>(r.pixel_depth.ptr);
-    sa.item_age = static_cast<double*>(r.item_age.ptr); sa.item_rgb = static_cast<const uint32_t*>(r.item_rgb.ptr);
-    sa.pixel_rgb = static_cast<uint32_t*>(r.pixel_rgb.ptr); sa.pixel_priority = static_cast<int32_t*>(r.pixel_priority.ptr);
-    sa.hist = reinterpret_cast<uint32_t*>(words + RC_WORDS_HIST); sa.totals = reinterpret_cast<long long*>(words + RC_WORDS_TOTALS);
-    PTR_TRY(grow(c, c->rc_page, (size_t)st * (size_t)(h + 2) * sizeof(double)));
-    sa.pixel_age = static_cast<double*>(c->rc_page.ptr);
-    HIP_TRY(c, launch_rc_shade(sa, s));
-
-    // directSamples: threshold and candidates on the GPU, the running sum of the picks here
-    RcLoopArgs a = rc_loop_args(r);
-    a.priority_max = (int)par->priority_max;
-    a.age_factor = par->age_factor; a.max_samples = par->max_samples_per_frame;
-    std::memcpy(a.from, view->from, sizeof a.from);
-    std::memcpy(a.world, view->world, sizeof a.world);
-    std::memcpy(a.proj_inv, view->proj_inv, sizeof a.proj_inv);
-    HIP_TRY(c, launch_rc_candidates(a, r.temp.ptr, r.temp.bytes, s));
-    HIP_TRY(c, hipMemcpyAsync(r.host_words, words, RC_WORDS_BYTES, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    RcLoopWords lw;
-    std::memcpy(&lw, r.host_words + RC_WORDS_LOOP, sizeof lw);
-    long long totals[3];
-    std::memcpy(totals, r.host_words + RC_WORDS_TOTALS, sizeof totals);
-    const double rf = lw.samples / par->max_samples_per_frame;          // :708
-    const double n_cand = (double)lw.candidates;
-    int n_picks = 0;
-    RcPickSegments segs;
-    bool closed_form = false;
-    if (lw.candidates > 0) {
-        if (!(rf > 0) || n_cand / rf > 4.0e9)
-            return fail(c, PTR_ERR_INVALID, "request factor %g with %d candidates: the reference's pick loop (Driver.js:795-822) would "
-                                            "not end", rf, lw.candidates);
-        long long np = 0;
-        closed_form = rc_pick_segments(rf, lw.candidates, &segs, &np);
-        if (closed_form) {
-            n_picks = (int)np;
-        } else {                                                        // (more pieces than the table holds: add the sum up here)
-            double index = 0, last_i = -1;                              // :795-822; lastI === null is the -1 here
-            while (index < n_cand) {
-                const double i = js_round(index);
-                if (i != last_i && i < n_cand) r.host_picks[n_picks++] = (int32_t)i;
-                last_i = i;
-                index += rf;
-            }
-            segs.n = 0;
-        }
-    }
-    a.n_picks = n_picks;
-    if (n_picks > 0) {
-        if (!closed_form) HIP_TRY(c, hipMemcpyAsync(r.picks.ptr, r.host_picks, (size_t)n_picks * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, launch_rc_requests(a, segs, r.temp.ptr, r.temp.bytes, s));
-        TraceArgs t;                                                    // requestSamples: Sample.doRaytracing for every request
-        std::memset(&t, 0, sizeof t);
-        t.scene = static_cast<const unsigned char*>(c->scenes.ptr);
-        t.dirs = a.dirs; t.n = n_picks; t.rc_mode = 1;
-        for (int k = 0; k < 3; k++) t.org[k] = view->from[k];
-        t.out_rgb = static_cast<double*>(r.tr_rgb.ptr); t.out_hit = static_cast<double*>(r.tr_hit.ptr);
-        HIP_TRY(c, launch_trace_batch_exact(t, s));
-    }
-    HIP_TRY(c, launch_rc_store(a, s));
-    HIP_TRY(c, hipMemcpyAsync(r.host_words + RC_WORDS_LOOP, words + RC_WORDS_LOOP, sizeof(RcLoopWords), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    std::memcpy(&lw, r.host_words + RC_WORDS_LOOP, sizeof lw);
-    out->threshold = lw.threshold < 0 ? std::nan("") : (double)lw.threshold;
-    out->request_factor = rf;
-    out->candidates = n_cand;
-    out->requests = (double)n_picks;
-    out->completeness = 100.0 * ((double)totals[0] / ((double)w * (double)h));        // :676
-    out->total_priority = (double)totals[1];
-    out->total_priority_increment = (double)totals[2];
-    out->cache_usage = (double)lw.used / (double)r.n_items;
-    return PTR_OK;
-}
-
-int ptr_rc_pick_sequence(double request_factor, int n_candidates, int32_t* out, int capacity)
-{
-    if (n_candidates < 0 || capacity < 0 || (capacity > 0 && !out)) return PTR_ERR_INVALID;
-    if (n_candidates == 0) return 0;
-    if (!(request_factor > 0) || (double)n_candidates / request_factor > 4.0e9) return PTR_ERR_INVALID;
-    RcPickSegments g;
-    long long n = 0;
-    if (!rc_pick_segments(request_factor, n_candidates, &g, &n)) return PTR_ERR_UNSUPPORTED;
-    if (n > capacity) return PTR_ERR_INVALID;
-    for (long long k = 0; k < n; k++) out[k] = rc_pick_at(g, k);
-    return (int)n;
-}
-
-int ptr_rc_get_frames(ptr_ctx* c, uint32_t* color_frame, uint32_t* reprojection_frame, uint32_t* priority_frame, uint32_t* sampling_frame)
-{
-    if (!c) return PTR_ERR_INVALID;
-    std::lock_guard<std::mutex> g(c->mu);
-    PTR_TRY(rc_cache_ready(c, true));
-    RcCache& r = *c->rcc;
-    uint32_t* host[4] = {color_frame, reprojection_frame, priority_frame, sampling_frame};
-    if (!host[0] && !host[1] && !host[2] && !host[3]) return PTR_OK;
-    HIP_TRY(c, hipSetDevice(c->device));
-    hipStream_t s = c->stream;
-    RcLoopArgs a = rc_loop_args(r);
-    const size_t px = (size_t)r.width * (size_t)r.height;
-    for (int k = 0; k < 4; k++) a.frames[k] = host[k] ? static_cast<uint32_t*>(r.frames.ptr) + (size_t)k * px : nullptr;
-    HIP_TRY(c, launch_rc_frames(a, s));
-    for (int k = 0; k < 4; k++)
-        if (host[k]) HIP_TRY(c, hipMemcpyAsync(host[k], a.frames[k], px * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    return PTR_OK;
-}
-
 int ptr_get_kernel_ms(ptr_ctx* c, float* main_ms, float* retrace_ms)
 {
     if (!c) return PTR_ERR_INVALID;
@@ -1615,408 +1031,6 @@ int ptr_get_stats(ptr_ctx* c, ptr_stats* out)
     HIP_TRY(c, hipMemcpy(w, c->stats_words, sizeof w, hipMemcpyDeviceToHost));
     out->primary = w[0]; out->hits = w[1]; out->shadow_rays = w[2];
     out->exit_tca = w[3]; out->exit_d2 = w[4]; out->exit_hit = w[5]; out->retraced = w[6]; out->reshaded = w[7]; out->secondary = w[8];
-    return PTR_OK;
-}
-
-
-// ---- multi-GPU gather over RCCL ---------------------------------------------------------------------------------
-extern "C++" {
-namespace {
-
-// The few RCCL entry points the gather needs, resolved at run time from librccl.so.1 (the process may already have one
-// loaded - PyTorch brings its own - and then that instance is the one used; a host without RCCL can still render on one GPU).
-// Types as in <rccl/rccl.h>: ncclComm_t is a pointer, ncclUniqueId 128 bytes passed by value, results and data types ints.
-struct RcclId { char internal[PTR_COMM_ID_BYTES]; };
-struct Rccl {
-    int (*GetUniqueId)(RcclId*) = nullptr;
-    int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
-    int (*CommInitAll)(void**, int, const int*) = nullptr;
-    int (*CommDestroy)(void*) = nullptr;
-    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
-    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
-    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
-    bool ok = false;
-    char why[256] = "";
-};
-constexpr int RCCL_UINT32 = 3;      // ncclUint32 (rccl.h: ncclInt8 0, ncclUint8 1, ncclInt32 2, ncclUint32 3)
-constexpr int RCCL_INT32 = 2, RCCL_FLOAT64 = 8;
-
-Rccl& rccl()
-{
-    static Rccl r;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-        if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-        if (!h) { snprintf(r.why, sizeof r.why, "cannot load librccl.so.1: %s", dlerror()); return; }
-        bool all = true;
-        auto sym = [&](const char* name) { void* p = dlsym(h, name); if (!p) { all = false; snprintf(r.why, sizeof r.why, "librccl.so.1 lacks %s", name); } return p; };
-        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
-        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
-        r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
-        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
-        r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
-        r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
-        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
-        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
-        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
-        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
-        r.ok = all;
-    });
-    return r;
-}
-
-#define RCCL_TRY(c, call)                                                                       \
-    do {                                                                                        \
-        int r_ = (call);                                                                        \
-        if (r_ != 0) return fail((c), PTR_ERR_HIP, "%s failed: %s", #call, rccl().GetErrorString(r_)); \
-    } while (0)
-
-struct GatherShape { int rows_max, rows; uint64_t stride; size_t count; };
-
-// sizes of one gather; fails on arguments that do not describe one.  part / n_parts = the context's rank / ranks.
-int gather_shape(ptr_ctx* c, int width, int height, int strip_height, int n_frames, uint64_t frame_stride_px, int part, int n_parts,
-                 GatherShape* g)
-{
-    if (width < 1 || height < 1 || strip_height < 1 || n_frames < 1 || n_frames > 65535 || width >= (1 << 24))
-        return fail(c, PTR_ERR_INVALID, "gather: bad sizes (width %d, height %d, strip_height %d, n_frames %d)", width, height, strip_height, n_frames);
-    const ptr_strips s0{n_parts, 0, strip_height, 0}, sp{n_parts, part, strip_height, 0};
-    g->rows_max = ptr_strip_rows(&s0, height);
-    g->rows = ptr_strip_rows(&sp, height);
-    if (g->rows_max < 0 || g->rows < 0 || g->rows_max > 65535) return fail(c, PTR_ERR_INVALID, "gather: bad strip partition");
-    g->stride = frame_stride_px ? frame_stride_px : (uint64_t)g->rows_max * (uint64_t)width;
-    if (g->stride < (uint64_t)g->rows_max * (uint64_t)width)
-        return fail(c, PTR_ERR_INVALID, "gather: frame_stride_px %llu is smaller than the largest part (%d rows of %d pixels)",
-                    (unsigned long long)g->stride, g->rows_max, width);
-    g->count = (size_t)g->stride * (size_t)n_frames;
-    if ((uint64_t)width * (uint64_t)height * (uint64_t)n_frames >= (1ull << 40)) return fail(c, PTR_ERR_INVALID, "gather: too many pixels");
-    return PTR_OK;
-}
-
-// the root's copy step for the rows of `part` that lie at src
-int gather_place(ptr_ctx* root, const uint32_t* src, uint32_t* full, int width, int height, int strip_height, int n_frames,
-                 const GatherShape& g, int part, int n_parts, hipStream_t s)
-{
-    GatherArgs a;
-    a.src = src; a.full = full; a.src_frame_stride_px = g.stride;
-    a.width = width; a.height = height; a.n_frames = n_frames;
-    a.strip_h = strip_height; a.n_parts = n_parts; a.part = part;
-    const ptr_strips sp{n_parts, part, strip_height, 0};
-    a.rows = ptr_strip_rows(&sp, height);
-    HIP_TRY(root, launch_gather_rows(a, s));
-    return PTR_OK;
-}
-
-}  // namespace
-}  // extern "C++"
-
-int ptr_comm_unique_id(unsigned char id[PTR_COMM_ID_BYTES])
-{
-    if (!id) return fail(nullptr, PTR_ERR_INVALID, "id is NULL");
-    Rccl& r = rccl();
-    if (!r.ok) return fail(nullptr, PTR_ERR_UNSUPPORTED, "%s", r.why);
-    RcclId u;
-    RCCL_TRY(nullptr, r.GetUniqueId(&u));
-    std::memcpy(id, u.internal, PTR_COMM_ID_BYTES);
-    return PTR_OK;
-}
-
-int ptr_comm_init_rank(ptr_ctx* c, const unsigned char id[PTR_COMM_ID_BYTES], int rank, int n_ranks)
-{
-    if (!c) return PTR_ERR_INVALID;
-    std::lock_guard<std::mutex> g(c->mu);
-    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(c, PTR_ERR_INVALID, "rank %d of %d", rank, n_ranks);
-    if (c->comm_n) return fail(c, PTR_ERR_INVALID, "the context already belongs to a communicator (ptr_comm_destroy first)");
-    if (n_ranks > 1) {
-        if (!id) return fail(c, PTR_ERR_INVALID, "id is NULL");
-        Rccl& r = rccl();
-        if (!r.ok) return fail(c, PTR_ERR_UNSUPPORTED, "%s", r.why);
-        HIP_TRY(c, hipSetDevice(c->device));
-        RcclId u;
-        std::memcpy(u.internal, id, PTR_COMM_ID_BYTES);
-        RCCL_TRY(c, r.CommInitRank(&c->comm, n_ranks, u, rank));
-    }
-    c->comm_rank = rank; c->comm_n = n_ranks;
-    return PTR_OK;
-}
-
-int ptr_comm_init_all(ptr_ctx* const* ctxs, int n)
-{
-    if (!ctxs || n < 1 || n > 64 || !ctxs[0]) return fail(nullptr, PTR_ERR_INVALID, "ptr_comm_init_all: bad context list");
-    for (int i = 0; i < n; i++) {                      // (messages go to ctxs[0], the context a host asks afterwards)
-        if (!ctxs[i]) return fail(ctxs[0], PTR_ERR_INVALID, "ptr_comm_init_all: context %d is NULL", i);
-        if (ctxs[i]->comm_n) return fail(ctxs[0], PTR_ERR_INVALID, "context %d already belongs to a communicator", i);
-        for (int j = 0; j < i; j++)
-            if (ctxs[j]->device == ctxs[i]->device)
-                return fail(ctxs[0], PTR_ERR_INVALID, "contexts %d and %d are on the same GPU (%d): one rank per GPU", j, i, ctxs[i]->device);
-    }
-    if (n > 1) {
-        Rccl& r = rccl();
-        if (!r.ok) return fail(ctxs[0], PTR_ERR_UNSUPPORTED, "%s", r.why);
-        void* comms[64];
-        int devs[64];
-        for (int i = 0; i < n; i++) devs[i] = ctxs[i]->device;
-        RCCL_TRY(ctxs[0], r.CommInitAll(comms, n, devs));
-        for (int i = 0; i < n; i++) ctxs[i]->comm = comms[i];
-    }
-    for (int i = 0; i < n; i++) { ctxs[i]->comm_rank = i; ctxs[i]->comm_n = n; }
-    return PTR_OK;
-}
-
-int ptr_comm_destroy(ptr_ctx* c)
-{
-    if (!c) return PTR_ERR_INVALID;
-    if (c->comm) {
-        (void)hipSetDevice(c->device);
-        (void)rccl().CommDestroy(c->comm);
-        c->comm = nullptr;
-    }
-    c->comm_n = 0; c->comm_rank = 0;
-    return PTR_OK;
-}
-
-// ---- reprojection of a cache split over several GPUs ---------------------------------------------------------------
-extern "C++" {
-namespace {
-int rc_shard_check(ptr_ctx* c, int n_local, int item_base)
-{
-    if (n_local < 0 || item_base < 0 || (long long)item_base + n_local >= (1ll << 31))
-        return fail(c, PTR_ERR_INVALID, "bad shard: %d items from %d", n_local, item_base);
-    return PTR_OK;
-}
-
-int rc_merge_enqueue(ptr_ctx* c, int width, int height, int n_ranks, int rank, const void* d_all_el, const void* d_all_dep, int n_local,
-                     int item_base, void* d_age, double age_factor, double depth_threshold, void* d_item_pixel, void* d_pel, void* d_pdep,
-                     hipStream_t s)
-{
-    const size_t cells = (size_t)(width + 2) * (size_t)(height + 2);
-    PTR_TRY(grow(c, c->rcm_before, cells * sizeof(double)));
-    if (n_local > 0 && c->rc_depth.bytes < (size_t)n_local * sizeof(double))
-        return fail(c, PTR_ERR_INVALID, "merge: no local pass of %d items ran on this context (ptr_rc_reproject_shard_device first)", n_local);
-    RcMergeArgs a;
-    std::memset(&a, 0, sizeof a);
-    a.width = width; a.height = height; a.n_items = n_local; a.item_base = item_base; a.n_ranks = n_ranks; a.rank = rank;
-    a.age_factor = age_factor; a.depth_threshold = depth_threshold;
-    a.all_depth = static_cast<const double*>(d_all_dep); a.all_element = static_cast<const int32_t*>(d_all_el);
-    a.age = static_cast<double*>(d_age); a.item_pixel = static_cast<int32_t*>(d_item_pixel);
-    a.item_depth = static_cast<const double*>(c->rc_depth.ptr);
-    a.pixel_element = static_cast<int32_t*>(d_pel); a.pixel_depth = static_cast<double*>(d_pdep);
-    a.before = static_cast<double*>(c->rcm_before.ptr);
-    HIP_TRY(c, launch_rc_merge(a, s));
-    return PTR_OK;
-}
-}  // namespace
-}  // extern "C++"
-
-int ptr_rc_reproject_shard_device(ptr_ctx* c, const ptr_rc_camera* cam, int n_local, int item_base, const void* d_hit_xyz, void* d_age,
-                                  double age_factor, double depth_threshold, void* d_item_pixel, void* d_local_element,
-                                  void* d_local_depth, void* stream)
-{
-    if (!c) return PTR_ERR_INVALID;
-    std::lock_guard<std::mutex> g(c->mu);
-    PTR_TRY(rc_check(c, cam, n_local, d_hit_xyz, d_age, d_item_pixel, d_local_element, d_local_depth));
-    PTR_TRY(rc_shard_check(c, n_local, item_base));
-    HIP_TRY(c, hipSetDevice(c->device));
-    return rc_enqueue(c, cam, n_local, static_cast<const double*>(d_hit_xyz), static_cast<double*>(d_age), age_factor, depth_threshold,
-                      static_cast<int32_t*>(d_item_pixel), static_cast<int32_t*>(d_local_element), static_cast<double*>(d_local_depth),
-                      stream ? static_cast<hipStream_t>(stream) : c->stream, item_base);
-}
-
-int ptr_rc_merge_shards_device(ptr_ctx* c, int width, int height, int n_ranks, int rank, const void* d_all_element, const void* d_all_depth,
-                               int n_local, int item_base, void* d_age, double age_factor, double depth_threshold, void* d_item_pixel,
-                               void* d_pixel_element, void* d_pixel_depth, void* stream)
-{
-    if (!c) return PTR_ERR_INVALID;
-    std::lock_guard<std::mutex> g(c->mu);
-    if (width < 1 || height < 1 || (long long)(width + 2) * (height + 2) >= (1ll << 31))
-        return fail(c, PTR_ERR_INVALID, "bad frame size %d x %d", width, height);
-    if (n_ranks < 1 || n_ranks > 64 || rank < 0 || rank >= n_ranks) return fail(c, PTR_ERR_INVALID, "merge: rank %d of %d", rank, n_ranks);
-    if (!d_all_element || !d_all_depth || !d_pixel_element || !d_pixel_depth || (n_local > 0 && (!d_age || !d_item_pixel)))
-        return fail(c, PTR_ERR_INVALID, "a required buffer is NULL");
-    PTR_TRY(rc_shard_check(c, n_local, item_base));
-    HIP_TRY(c, hipSetDevice(c->device));
-    return rc_merge_enqueue(c, width, height, n_ranks, rank, d_all_element, d_all_depth, n_local, item_base, d_age, age_factor,
-                            depth_threshold, d_item_pixel, d_pixel_element, d_pixel_depth, stream ? static_cast<hipStream_t>(stream) : c->stream);
-}
-
-int ptr_rc_reproject_multi_device(ptr_ctx* c, const ptr_rc_camera* cam, int n_local, int item_base, const void* d_hit_xyz, void* d_age,
-                                  double age_factor, double depth_threshold, void* d_item_pixel, void* d_pixel_element,
-                                  void* d_pixel_depth, void* stream)
-{
-    if (!c) return PTR_ERR_INVALID;
-    std::lock_guard<std::mutex> g(c->mu);
-    if (c->comm_n < 1) return fail(c, PTR_ERR_INVALID, "the context belongs to no communicator (ptr_comm_init_rank / _all)");
-    PTR_TRY(rc_check(c, cam, n_local, d_hit_xyz, d_age, d_item_pixel, d_pixel_element, d_pixel_depth));
-    PTR_TRY(rc_shard_check(c, n_local, item_base));
-    HIP_TRY(c, hipSetDevice(c->device));
-    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
-    const int n = c->comm_n, me = c->comm_rank;
-    const size_t cells = (size_t)(cam->width + 2) * (size_t)(cam->height + 2);
-    PTR_TRY(grow(c, c->rcm_all_el, (size_t)n * cells * sizeof(int32_t)));
-    PTR_TRY(grow(c, c->rcm_all_dep, (size_t)n * cells * sizeof(double)));
-    int32_t* all_el = static_cast<int32_t*>(c->rcm_all_el.ptr);
-    double* all_dep = static_cast<double*>(c->rcm_all_dep.ptr);
-    // the local pass writes straight into this rank's place of the gathered grids when it is alone; otherwise into a
-    // buffer of its own (ncclAllGather's send buffer must not lie inside the receive buffer except at its own offset)
-    int32_t* loc_el = all_el + (size_t)me * cells;
-    double* loc_dep = all_dep + (size_t)me * cells;
-    PTR_TRY(rc_enqueue(c, cam, n_local, static_cast<const double*>(d_hit_xyz), static_cast<double*>(d_age), age_factor, depth_threshold,
-                       static_cast<int32_t*>(d_item_pixel), loc_el, loc_dep, s, item_base));
-    if (n > 1) {
-        Rccl& r = rccl();
-        if (!r.ok) return fail(c, PTR_ERR_UNSUPPORTED, "%s", r.why);
-        RCCL_TRY(c, r.GroupStart());                                    // in place: each rank's grid already sits at its offset
-        const int rc1 = r.AllGather(loc_el, all_el, cells, RCCL_INT32, c->comm, s);
-        const int rc2 = rc1 == 0 ? r.AllGather(loc_dep, all_dep, cells, RCCL_FLOAT64, c->comm, s) : 0;
-        const int rc3 = r.GroupEnd();
-        if (rc1 != 0 || rc2 != 0 || rc3 != 0)
-            return fail(c, PTR_ERR_HIP, "ncclAllGather failed: %s", r.GetErrorString(rc1 ? rc1 : rc2 ? rc2 : rc3));
-    }
-    return rc_merge_enqueue(c, cam->width, cam->height, n, me, all_el, all_dep, n_local, item_base, d_age, age_factor, depth_threshold,
-                            d_item_pixel, d_pixel_element, d_pixel_depth, s);
-}
-
-int ptr_gather_strips_device(ptr_ctx* c, int width, int height, int strip_height, int n_frames,
-                             const void* d_local, uint64_t frame_stride_px, void* d_full, int root, void* stream)
-{
-    if (!c) return PTR_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(c->mu);
-    if (c->comm_n < 1) return fail(c, PTR_ERR_INVALID, "gather: the context belongs to no communicator (ptr_comm_init_rank / _all)");
-    const int n = c->comm_n, me = c->comm_rank;
-    if (root < 0 || root >= n) return fail(c, PTR_ERR_INVALID, "gather: root %d of %d ranks", root, n);
-    if (!d_local || (me == root && !d_full)) return fail(c, PTR_ERR_INVALID, "gather: a required buffer is NULL");
-    GatherShape g;
-    PTR_TRY(gather_shape(c, width, height, strip_height, n_frames, frame_stride_px, me, n, &g));
-    HIP_TRY(c, hipSetDevice(c->device));
-    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
-    uint32_t* stage = nullptr;
-    if (me == root && n > 1) {
-        PTR_TRY(grow(c, c->gather_stage, (size_t)(n - 1) * g.count * sizeof(uint32_t)));
-        stage = static_cast<uint32_t*>(c->gather_stage.ptr);
-    }
-    if (n > 1) {
-        // a direct gather: every peer sends over its own xGMI link to the root; one group, so the transfers run side by side
-        Rccl& r = rccl();
-        RCCL_TRY(c, r.GroupStart());
-        int rc = 0;
-        if (me == root) {
-            int slot = 0;
-            for (int p = 0; p < n && rc == 0; p++)
-                if (p != root) rc = r.Recv(stage + (size_t)(slot++) * g.count, g.count, RCCL_UINT32, p, c->comm, s);
-        } else {
-            rc = r.Send(d_local, g.count, RCCL_UINT32, root, c->comm, s);
-        }
-        const int rc2 = r.GroupEnd();
-        if (rc != 0 || rc2 != 0) return fail(c, PTR_ERR_HIP, "gather: ncclSend/ncclRecv failed: %s", r.GetErrorString(rc ? rc : rc2));
-    }
-    if (me == root) {
-        int slot = 0;
-        for (int p = 0; p < n; p++) {
-            const uint32_t* src = p == root ? static_cast<const uint32_t*>(d_local) : stage + (size_t)(slot++) * g.count;
-            PTR_TRY(gather_place(c, src, static_cast<uint32_t*>(d_full), width, height, strip_height, n_frames, g, p, n, s));
-        }
-    }
-    return PTR_OK;
-}
-
-int ptr_place_strips_device(ptr_ctx* c, const ptr_strips* st, int width, int height, int n_frames,
-                            const void* d_part, uint64_t frame_stride_px, void* d_full, void* stream)
-{
-    if (!c) return PTR_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(c->mu);
-    if (!st || st->n_parts < 1 || st->part < 0 || st->part >= st->n_parts) return fail(c, PTR_ERR_INVALID, "place: bad strip description");
-    if (!d_part || !d_full) return fail(c, PTR_ERR_INVALID, "place: a required buffer is NULL");
-    GatherShape g;
-    PTR_TRY(gather_shape(c, width, height, st->strip_height, n_frames, 0, st->part, st->n_parts, &g));
-    g.stride = frame_stride_px ? frame_stride_px : (uint64_t)g.rows * (uint64_t)width;
-    if (g.stride < (uint64_t)g.rows * (uint64_t)width) return fail(c, PTR_ERR_INVALID, "place: frame_stride_px smaller than the part");
-    HIP_TRY(c, hipSetDevice(c->device));
-    return gather_place(c, static_cast<const uint32_t*>(d_part), static_cast<uint32_t*>(d_full), width, height, st->strip_height,
-                        n_frames, g, st->part, st->n_parts, stream ? static_cast<hipStream_t>(stream) : c->stream);
-}
-
-int ptr_gather_strips_all(ptr_ctx* const* ctxs, int n, int width, int height, int strip_height, int n_frames,
-                          const void* const* d_locals, uint64_t frame_stride_px, void* d_full)
-{
-    if (!ctxs || n < 1 || !ctxs[0]) return PTR_ERR_INVALID;
-    ptr_ctx* root = ctxs[0];
-    if (!d_locals || !d_full) return fail(root, PTR_ERR_INVALID, "gather: a required buffer is NULL");
-    for (int i = 0; i < n; i++)
-        if (!ctxs[i] || ctxs[i]->comm_n != n || ctxs[i]->comm_rank != i || !d_locals[i])
-            return fail(root, PTR_ERR_INVALID, "gather: context %d is not rank %d of a communicator of %d (ptr_comm_init_all), or its buffer is NULL", i, i, n);
-    GatherShape g;
-    PTR_TRY(gather_shape(root, width, height, strip_height, n_frames, frame_stride_px, 0, n, &g));
-    uint32_t* stage = nullptr;
-    if (n > 1) {
-        HIP_TRY(root, hipSetDevice(root->device));
-        PTR_TRY(grow(root, root->gather_stage, (size_t)(n - 1) * g.count * sizeof(uint32_t)));
-        stage = static_cast<uint32_t*>(root->gather_stage.ptr);
-        Rccl& r = rccl();
-        RCCL_TRY(root, r.GroupStart());
-        int rc = 0;
-        for (int i = 1; i < n && rc == 0; i++) {
-            rc = r.Recv(stage + (size_t)(i - 1) * g.count, g.count, RCCL_UINT32, i, root->comm, root->stream);
-            if (rc == 0) rc = r.Send(d_locals[i], g.count, RCCL_UINT32, 0, ctxs[i]->comm, ctxs[i]->stream);
-        }
-        const int rc2 = r.GroupEnd();
-        if (rc != 0 || rc2 != 0) return fail(root, PTR_ERR_HIP, "gather: ncclSend/ncclRecv failed: %s", r.GetErrorString(rc ? rc : rc2));
-    }
-    HIP_TRY(root, hipSetDevice(root->device));
-    for (int i = 0; i < n; i++) {
-        const uint32_t* src = i == 0 ? static_cast<const uint32_t*>(d_locals[0]) : stage + (size_t)(i - 1) * g.count;
-        PTR_TRY(gather_place(root, src, static_cast<uint32_t*>(d_full), width, height, strip_height, n_frames, g, i, n, root->stream));
-    }
-    return PTR_OK;
-}
-
-int ptr_render_multi(ptr_ctx* const* ctxs, int n, const ptr_params* p, uint32_t* out_rgba8)
-{
-    if (!ctxs || n < 1 || !ctxs[0]) return PTR_ERR_INVALID;
-    ptr_ctx* root = ctxs[0];
-    if (!p || !out_rgba8) return fail(root, PTR_ERR_INVALID, "ptr_render_multi: params / out_rgba8 is NULL");
-    if (p->start_y != 0 || p->scan_height != p->height || (p->flags & PTR_QUIRK_ROW_SHIFT))
-        return fail(root, PTR_ERR_INVALID, "ptr_render_multi renders whole frames: start_y 0, scan_height == height, no PTR_QUIRK_ROW_SHIFT");
-    for (int i = 0; i < n; i++)
-        if (!ctxs[i] || ctxs[i]->comm_n != n || ctxs[i]->comm_rank != i)
-            return fail(root, PTR_ERR_INVALID, "ptr_render_multi: context %d is not rank %d of a communicator of %d (ptr_comm_init_all)", i, i, n);
-    constexpr int STRIP = 8;
-    const ptr_strips s0{n, 0, STRIP, 0};
-    const int rows_max = ptr_strip_rows(&s0, p->height);
-    if (rows_max < 1) return fail(root, PTR_ERR_INVALID, "ptr_render_multi: bad height %d", p->height);
-    const uint64_t stride = (uint64_t)rows_max * (uint64_t)p->width;
-    const void* locals[64];
-    for (int i = 0; i < n; i++) {
-        ptr_ctx* c = ctxs[i];
-        std::lock_guard<std::mutex> lk(c->mu);
-        const ptr_strips sp{n, i, STRIP, 0};
-        ptr_params q = *p;
-        q.scan_height = ptr_strip_rows(&sp, p->height);
-        HIP_TRY(c, hipSetDevice(c->device));
-        PTR_TRY(grow(c, c->multi_local, (size_t)stride * sizeof(uint32_t)));
-        locals[i] = c->multi_local.ptr;
-        if (q.scan_height < 1) continue;                       // more GPUs than strips: nothing to render here
-        int rc = check_params(c, &q, 0, 1);
-        if (rc == PTR_OK) rc = enqueue_render(c, &q, 0, 1, static_cast<uint32_t*>(c->multi_local.ptr), nullptr, c->stream, &sp, stride);
-        if (rc != PTR_OK) { if (c != root) fail(root, rc, "ptr_render_multi, GPU %d: %s", c->device, c->err); return rc; }
-    }
-    const size_t px = (size_t)p->width * (size_t)p->height;
-    {
-        std::lock_guard<std::mutex> lk(root->mu);
-        HIP_TRY(root, hipSetDevice(root->device));
-        PTR_TRY(grow(root, root->multi_full, px * sizeof(uint32_t)));
-    }
-    PTR_TRY(ptr_gather_strips_all(ctxs, n, p->width, p->height, STRIP, 1, locals, stride, root->multi_full.ptr));
-    std::lock_guard<std::mutex> lk(root->mu);
-    HIP_TRY(root, hipSetDevice(root->device));
-    HIP_TRY(root, hipMemcpyAsync(out_rgba8, root->multi_full.ptr, px * sizeof(uint32_t), hipMemcpyDeviceToHost, root->stream));
-    HIP_TRY(root, hipStreamSynchronize(root->stream));
-    for (int i = 1; i < n; i++) {                              // the peers' sends are done once the root has everything; leave no work behind
-        HIP_TRY(ctxs[i], hipSetDevice(ctxs[i]->device));
-        HIP_TRY(ctxs[i], hipStreamSynchronize(ctxs[i]->stream));
-    }
     return PTR_OK;
 }
 

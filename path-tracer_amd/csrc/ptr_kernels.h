@@ -40,5 +40,7 @@ hipError_t launch_rc_frames(const RcLoopArgs& a, hipStream_t s);
 
 // multi-GPU gather: one part's compact rows -> their places in the whole frames (ptr_kernels_gather.hip)
 hipError_t launch_gather_rows(const GatherArgs& a, hipStream_t s);
+// zero a run of 32-bit words by a kernel (graph-capture safe where a memset node is not; ptr_kernels_gather.hip)
+hipError_t launch_clear_words(void* p, size_t bytes, hipStream_t s);
 
 }  // namespace ptr

@@ -34,4 +34,23 @@ hipError_t launch_gather_rows(const GatherArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 
+// Zeroes n_words 32-bit words (16 bytes per lane where the count allows it).  ptr_render_device_noalloc clears its counter
+// and statistics words with this kernel rather than with hipMemsetAsync: recorded into a HIP graph, a memset node of this
+// size left garbage in the words from the second replay on (ROCm 7.0 / 7.2, measured: tools/diag_capture.py); a kernel node
+// replays as it was recorded.
+__global__ void __launch_bounds__(256) clear_words_kernel(uint32_t* p, uint32_t n_words)
+{
+    const uint32_t k = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    if (k + 4u <= n_words) *reinterpret_cast<uint4*>(p + k) = make_uint4(0u, 0u, 0u, 0u);
+    else for (uint32_t j = k; j < n_words; j++) p[j] = 0u;
+}
+
+hipError_t launch_clear_words(void* p, size_t bytes, hipStream_t s)          // p 16-byte aligned, bytes a multiple of 4
+{
+    const uint32_t n_words = (uint32_t)(bytes / 4);
+    if (n_words == 0) return hipSuccess;
+    hipLaunchKernelGGL(clear_words_kernel, dim3((n_words + 1023u) / 1024u), dim3(256), 0, s, static_cast<uint32_t*>(p), n_words);
+    return hipGetLastError();
+}
+
 }  // namespace ptr

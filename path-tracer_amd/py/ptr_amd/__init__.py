@@ -30,7 +30,7 @@ SYMBOLS = [
     "ptr_set_background", "ptr_set_background_f64", "ptr_set_camera", "ptr_set_extension_f64",
     "ptr_render", "ptr_render_device", "ptr_render_device_noalloc", "ptr_render_strips_device", "ptr_strip_rows", "ptr_strip_image_row", "ptr_sync",
     "ptr_trace_batch", "ptr_trace_batch_f64", "ptr_trace_samples_f64", "ptr_rc_reproject", "ptr_rc_reproject_device", "ptr_rc_shade", "ptr_rc_shade_device", "ptr_get_stats", "ptr_get_kernel_ms",
-    "ptr_comm_unique_id", "ptr_comm_init_rank", "ptr_comm_init_all", "ptr_comm_destroy",
+    "ptr_gather_plan", "ptr_comm_unique_id", "ptr_comm_init_rank", "ptr_comm_init_all", "ptr_comm_destroy",
     "ptr_gather_strips_device", "ptr_gather_strips_all", "ptr_place_strips_device", "ptr_render_multi",
     "ptr_rc_cache_create", "ptr_rc_cache_destroy", "ptr_rc_cache_shape", "ptr_rc_cache_upload", "ptr_rc_cache_download",
     "ptr_rc_next_frame", "ptr_rc_get_frames", "ptr_rc_pick_sequence",
@@ -83,6 +83,23 @@ RC_STATE = (("item_pixel", np.int32, "n"), ("item_hit", np.float64, "3n"), ("ite
 class Strips(C.Structure):
     _fields_ = [("n_parts", C.c_int32), ("part", C.c_int32), ("strip_height", C.c_int32),
                 ("reserved", C.c_int32)]
+
+
+class GatherSizes(C.Structure):
+    _fields_ = [("rows_max", C.c_int32), ("rows", C.c_int32), ("frame_stride_px", C.c_uint64), ("count", C.c_uint64),
+                ("local_bytes", C.c_uint64), ("root_stage_bytes", C.c_uint64), ("full_bytes", C.c_uint64),
+                ("last_full_index", C.c_uint64)]
+
+
+def gather_plan(width, height, strip_height, n_frames, part, n_parts, frame_stride_px=0):
+    """ptr_gather_plan: the sizes of one strip gather (host arithmetic only; works without a GPU)."""
+    g = GatherSizes()
+    L = lib()
+    L.ptr_gather_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.POINTER(GatherSizes)]
+    rc = L.ptr_gather_plan(width, height, strip_height, n_frames, frame_stride_px, part, n_parts, C.byref(g))
+    if rc != 0:
+        raise PtrError(rc, L.ptr_last_error(None).decode())
+    return {k: int(getattr(g, k)) for k, _ in GatherSizes._fields_}
 
 
 class StripPart:

@@ -97,3 +97,40 @@ def test_sharded_reprojection_gloo(world):
     ret = mgr.dict()
     mp.spawn(_reproject_worker, args=(world, 29720 + world, ret), nprocs=world, join=True)
     assert ret.get("ok") is True
+
+
+def test_gather_sizes_at_eight_ranks_and_headline_batch():
+    """The strip gather's host arithmetic (ptr_gather_plan = what ptr_gather_strips_device / _all compute) at sizes no test
+    box holds: bench.py's headline at N = 8 (2 048 frames of 1920 x 1080 per step, 8-row strips: parts of 136 / 128 rows) and
+    BASELINE configs[3] (8 frames of 3840 x 2160).  Everything is checked against Python's unbounded integers: a 32-bit
+    product anywhere in the chain (count = stride x frames, the root's staging offsets, the copy kernel's pixel index)
+    would show as a mismatch here before the first real 8-GPU run."""
+    sys.path[:0] = [os.path.join(ROOT, "path-tracer_amd", "py")]
+    import ptr_amd
+    for (w, h, frames, n) in ((1920, 1080, 256 * 8, 8), (3840, 2160, 8, 8), (1920, 1080, 256 * 2, 2), (1920, 1080, 65535, 8)):
+        strips = -(-h // 8)
+        rows_of = [sum(min(8, h - 8 * k) for k in range(r, strips, n)) for r in range(n)]
+        total_stage = 0
+        for r in range(n):
+            g = ptr_amd.gather_plan(w, h, 8, frames, r, n)
+            assert g["rows"] == rows_of[r] == ptr_amd.StripPart(n, r, 8).local_rows(h)
+            assert g["rows_max"] == rows_of[0] == max(rows_of)
+            assert g["frame_stride_px"] == rows_of[0] * w
+            assert g["count"] == rows_of[0] * w * frames
+            assert g["local_bytes"] == 4 * rows_of[0] * w * frames
+            assert g["root_stage_bytes"] == (n - 1) * 4 * rows_of[0] * w * frames
+            assert g["full_bytes"] == 4 * w * h * frames
+            last_row = ptr_amd.StripPart(n, r, 8).global_rows(h)[-1]
+            assert g["last_full_index"] == ((frames - 1) * h + last_row) * w + (w - 1)
+            assert g["last_full_index"] < w * h * frames
+            total_stage += g["local_bytes"]
+        if (w, h, frames, n) == (1920, 1080, 2048, 8):
+            assert rows_of == [136, 136, 136, 136, 136, 136, 136, 128]
+            assert g["count"] == 534_773_760 and g["root_stage_bytes"] == 14_973_665_280      # > 2^32: the point of this test
+            assert g["full_bytes"] == 16_986_931_200 and g["last_full_index"] > 2 ** 31      # (a signed 32-bit index would wrap)
+        if frames == 65535:
+            assert g["last_full_index"] > 2 ** 32 and g["count"] > 2 ** 32
+    # arguments that describe no gather are refused, not wrapped
+    for bad in ((0, 1080, 8, 1, 0, 8), (1920, 1080, 8, 70000, 0, 8), (1920, 1080, 8, 1, 8, 8), (1920, 1080, 8, 1, 0, 65), (1 << 24, 8, 8, 1, 0, 2)):
+        with pytest.raises(ptr_amd.PtrError):
+            ptr_amd.gather_plan(*bad)
