@@ -444,6 +444,11 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
                    uint32_t* d_out8, float* d_out32f, hipStream_t s,
                    const ptr_strips* strips, uint64_t frame_stride_px, bool fixed_ws)
 {
+    // (the plan reads c->needs_exact, which the upload of a changed scene sets: upload first, where uploading is allowed)
+    if (!fixed_ws) {
+        PTR_TRY(order_after_last(c, s));      // queue, counters and stats words are shared by all calls on the context
+        PTR_TRY(ensure_uploaded(c, s));
+    }
     const RenderPlan plan = plan_render(c, p, n_frames);
     if (fixed_ws) {
         // every reason to refuse the call comes first: a refused call enqueues nothing and leaves the shared array, and
@@ -460,13 +465,12 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
                                             "(about 3.9 M at most), or use ptr_render_device",
                         need, NOALLOC_SCRATCH_BYTES - NOALLOC_QUEUE_OFFSET);
     }
-    PTR_TRY(order_after_last(c, s));          // queue, counters and stats words are shared by all calls on the context
     if (fixed_ws) {
+        PTR_TRY(order_after_last(c, s));      // queue, counters and stats words are shared by all calls on the context
         // every call on this GPU shares the array and finds the last call's contents in it: clear what must start at zero
         // (by a kernel, not hipMemsetAsync: as a HIP graph's memset node the clear came out wrong from the second replay on)
         HIP_TRY(c, launch_clear_words(c->scratch_dev, WORDS_BYTES, s));
     } else {
-        PTR_TRY(ensure_uploaded(c, s));
         PTR_TRY(ensure_words(c, s));
     }
 
@@ -589,7 +593,8 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
                         : launch_render_fast(a, n_frames, (p->flags & PTR_MODE_TOLERANT) ? 2 : 1, s);
     if (e == hipSuccess && timing) e = hipEventRecord(c->ev[1], s);
     if (e == hipSuccess) {
-        e = many ? launch_retrace_exact(a, 8, 8, s) : launch_retrace_exact(a, 1, 4, s);
+        const bool tol = !many && (p->flags & PTR_MODE_TOLERANT);       // (no shading-only entries: one launch fewer)
+        e = many ? launch_retrace_exact(a, 8, 8, s) : launch_retrace_exact(a, tol ? 0 : 1, 4, s);
         if (e == hipSuccess && timing) { e = hipEventRecord(c->ev[2], s); c->timed_kernels = 2; }
     }
     if (e != hipSuccess) {

@@ -296,7 +296,9 @@ __global__ void __launch_bounds__(PTR_BLOCK) retrace_exact_kernel(RenderArgs a)
     constexpr uint32_t kind = (uint32_t)KIND;
     const uint32_t part = blockIdx.y;
     const uint32_t nparts = gridDim.y;
-    if (threadIdx.x == 0 && part == 0) a.counter_next[sub * PTR_COUNTER_STRIDE + kind] = 0u;
+    // (the full re-trace always runs, the shading-only re-do only in the mode that has such entries: the first clears both of
+    // the other set's words for the next call)
+    if (threadIdx.x == 0 && part == 0 && KIND == 0) { a.counter_next[sub * PTR_COUNTER_STRIDE] = 0u; a.counter_next[sub * PTR_COUNTER_STRIDE + 1] = 0u; }
     if (sub >= a.n_queues) return;
     const uint32_t fill = a.counter[sub * PTR_COUNTER_STRIDE + kind];
     const uint32_t count = fill < a.queue_capacity ? fill : a.queue_capacity;
@@ -411,7 +413,7 @@ hipError_t launch_retrace_exact(const RenderArgs& a0, int parts1, int parts0, hi
 {
     const RenderArgs& a = a0;
     hipLaunchKernelGGL(retrace_exact_kernel<0>, dim3(PTR_MAX_QUEUES, parts0, 1), dim3(PTR_BLOCK), 0, s, a);
-    hipLaunchKernelGGL(retrace_exact_kernel<1>, dim3(PTR_MAX_QUEUES, parts1, 1), dim3(PTR_BLOCK), 0, s, a);
+    if (parts1 > 0) hipLaunchKernelGGL(retrace_exact_kernel<1>, dim3(PTR_MAX_QUEUES, parts1, 1), dim3(PTR_BLOCK), 0, s, a);   // (0: no shading-only entries in this mode)
     return hipGetLastError();
 }
 

@@ -472,6 +472,7 @@ async function gpuTests() {
         const elements = buildExample1().getElements().map(el => el.serialize());
         const url = new URL('../src/RenderWorker.js', import.meta.url);
         const workers = [0, 1].map(() => new Worker(url, { workerData: { device: 0 } }));
+        const exited = workers.map(w => new Promise(resolve => w.once('exit', resolve)));      // (listening from the start: a thread may be gone before the checks below are done)
         const band = Math.floor(m.height / m.jobs);
         const got = Buffer.alloc(want.length);
         await Promise.all(workers.map((w, k) => new Promise((resolve, reject) => {
@@ -495,7 +496,7 @@ async function gpuTests() {
             next();
         })));
         assert.ok(sameBytes(got, want));
-        await Promise.all(workers.map(w => new Promise(resolve => w.once('exit', resolve))));     // 'close' ends the threads
+        await Promise.all(exited);                                                               // 'close' ends the threads
     });
     await atest('RenderPlanner {workerThreads: true}: the reference\'s planner over real Workers, bytes equal the reference bands', async () => {
         const m = index.bands['example1@320x240/8'];
