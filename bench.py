@@ -43,11 +43,17 @@ STRIP = 8
 PEAK_FP32_VALU_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
 PEAK_HBM_GBPS = 8000.0
 # HBM traffic of the float32 kernel per pixel, from the PMC passes of this very command kept under profiles/
-# (r02_summary.md: WRITE_SIZE 2 581 240 KB and FETCH_SIZE 9 680.6 KB per launch of 256 x 1920 x 1080 pixels; gfx950
+# (r03_summary.md, kernel render_fast_kernel<2, false, 4, false, false>: WRITE_SIZE 2 092 060 KB and FETCH_SIZE 4 122.4 KB per
+# launch of 256 x 1920 x 1080 pixels; render_fast_kernel<1, false, 3, ...> of --mode exact: 2 305 220 KB and 5 725.1 KB; gfx950
 # correction of the guide applied: FETCH_SIZE counts 64 B per 128-B request -> x 2).  Counters cannot be read from
 # inside this process, so the per-launch figure reported below is this profiled rate times the launch's pixels
 # (reported as "traffic", with "traffic_source" saying so).
-PROFILED_HBM_BYTES_PER_PIXEL = (2581240.0 * 1024 + 2 * 9680.56 * 1024) / (256 * 1920 * 1080)
+PROFILED_HBM_BYTES_PER_PIXEL = {"tolerant": (2092060.0 * 1024 + 2 * 4122.44 * 1024) / (256 * 1920 * 1080),
+                                "exact": (2305220.0 * 1024 + 2 * 5725.1 * 1024) / (256 * 1920 * 1080)}
+# ... and of one reprojection pass over the 1920 x 1080 x 4 cache on one GPU (same profile: rc_clear + rc_project + hipCUB's five
+# radix-sort kernels + rc_resolve; FETCH_SIZE 11.5 + 129 620 + 5 x 33 000.9 + 328 300 KB, x 2; WRITE_SIZE 24 840 + 209 808 +
+# 5 x 60 107.8 + 142 813 KB): 1.97 GB against 0.39 GB algorithmic
+PROFILED_RC_BYTES_PER_PASS = int((2 * (11.5 + 129620 + 5 * 33000.9 + 328300) + (24840 + 209808 + 5 * 60107.8 + 142813)) * 1024)
 
 
 def example1_soa():
@@ -248,6 +254,11 @@ def rc_reprojection_line(ptr_amd, torch, dist, rdr, world, rank, backend, librar
             "checked": "grid and rank 0's items equal the single-GPU pass over the whole cache",
             "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                          "frac": round(alg / ms / 1e6 / PEAK_HBM_GBPS, 4), "algorithmic_bytes": alg,
+                         "traffic": PROFILED_RC_BYTES_PER_PASS if world == 1 else None,
+                         "traffic_source": "not measured in this run: PMC bytes of one pass in the profiled run of this command "
+                                           "(profiles/r03_summary.md, WRITE_SIZE + 2 x FETCH_SIZE over the pass's nine kernels); "
+                                           "5 x the algorithmic bytes: the three radix-sort passes and the gathers by cache index "
+                                           "(profiles/r03_rc_reproject.md)" if world == 1 else "no profile of the sharded pass",
                          "note": "algorithmic bytes of the whole cache / the wall time of a pass (all ranks, exchange included)"}}
 
 
@@ -687,9 +698,9 @@ def main():
                          "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
                          "frac_step": round(launch_flops / (elapsed / args.steps) / 1e12 / PEAK_FP32_VALU_TFLOPS, 4),
-                         "traffic": int(PROFILED_HBM_BYTES_PER_PIXEL * WIDTH * local_rows * frames_total),
+                         "traffic": int(PROFILED_HBM_BYTES_PER_PIXEL["tolerant" if head_flags else "exact"] * WIDTH * local_rows * frames_total),
                          "traffic_source": "not measured in this run: PMC bytes per pixel of the profiled run of this command "
-                                           "(profiles/r02_summary.md, WRITE_SIZE + 2 x FETCH_SIZE passes) x pixels of this "
+                                           "(profiles/r03_summary.md, WRITE_SIZE + 2 x FETCH_SIZE passes) x pixels of this "
                                            "launch; algorithmic bytes = 4 per pixel",
                          "kernel_ms": round(main_ms, 4), "retrace_kernel_ms": round(retrace_ms, 4),
                          "algorithmic_flops_per_launch": int(launch_flops),
