@@ -66,6 +66,9 @@ extern "C" {
 /* Diagnostics/tests: use the many-sphere float32 kernel (sphere list staged through LDS, chosen by
  * itself above 12 spheres) whatever the sphere count.  Same results contract as the default.     */
 #define PTR_DEBUG_FORCE_MANY  0x4000u
+/* Diagnostics/tests: render an extension mode's float64 form with the lane-by-lane kernel (the specification written out per
+ * pixel) instead of the wave-level one that sphere scenes take by default.  Same bytes: the tests compare the two.           */
+#define PTR_DEBUG_EXT_LANEWISE 0x1000u
 
 typedef struct ptr_ctx ptr_ctx;
 

@@ -554,7 +554,8 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
         // error bounds yet that would tell which pixels to re-do (errors grow with every bounce off a curved surface), and
         // the contract is <= 1/255 on every pixel.  PTR_MODE_F32_ONLY asks for the float32 throughput form explicitly.
         a.max_depth = p->max_depth; a.spp = p->spp; a.seed = p->seed;
-        HIP_TRY(c, launch_render_ext(a, n_frames, exact || !(p->flags & PTR_MODE_F32_ONLY), stats, c->n_planes == 0 && c->n_phong == 0, s));
+        HIP_TRY(c, launch_render_ext(a, n_frames, exact || !(p->flags & PTR_MODE_F32_ONLY), stats, c->n_planes == 0 && c->n_phong == 0,
+                                     (p->flags & PTR_DEBUG_EXT_LANEWISE) != 0, s));
         if (timing) { HIP_TRY(c, hipEventRecord(c->ev[1], s)); c->timed_kernels = 1; }
         return mark_launch(c, s);
     }

@@ -22,7 +22,7 @@ hipError_t launch_render_many(const RenderArgs& a, int n_frames, bool hybrid, hi
 int many_kernel_rows_per_block();
 
 // extension modes: reflection/refraction to max_depth, Philox-jittered spp (ptr_kernels_ext.hip)
-hipError_t launch_render_ext(const RenderArgs& a, int n_frames, bool f64, bool stats, bool spheres_only, hipStream_t s);   // spheres_only: no planes, no Phong terms
+hipError_t launch_render_ext(const RenderArgs& a, int n_frames, bool f64, bool stats, bool spheres_only, bool lanewise, hipStream_t s);   // spheres_only: no planes, no Phong terms; lanewise: PTR_DEBUG_EXT_LANEWISE
 
 // render cache reprojection pass (ptr_kernels_rc.hip)
 hipError_t launch_rc_shade(const RcShadeArgs& a, hipStream_t s);

@@ -708,12 +708,306 @@ __global__ void __launch_bounds__(64) PTR_EXT_OCC render_ext_f32_kernel(RenderAr
 #endif
 __global__ void __launch_bounds__(64) PTR_EXT_GEN_OCC render_ext_f32_gen_kernel(RenderArgs a) { render_ext_f32_body<true>(a); }
 
-hipError_t launch_render_ext(const RenderArgs& a, int n_frames, bool f64, bool stats, bool spheres_only, hipStream_t s)
+// ---- the float64 specification in the wave-level form (scenes of spheres) ---------------------------------------------
+// Bit for bit what trace_ext<double> computes - every lane performs the same float64 operations in the same order - but
+// the wave gets through the two sphere loops the way the float32 form does:
+//   * the sphere records (SphereG64: centre, radius^2) arrive by scalar loads on a wave-uniform index, one ahead of their use;
+//   * Sphere.intersect's two early exits (Sphere.js:18-25) become one lane mask, the square root runs only when some lane hits;
+//   * the camera ray's pass visits only the spheres its 8 x 8 tile can reach, the shadow loop skips the occluders whose
+//     (light, occluder) cone the line through the light misses (PairQ).  Both culls only remove CERTAIN misses (their margins
+//     are float32 error bands, orders of magnitude above float64 rounding), lanes whose N.L is not positive are not tested
+//     (their term is (colour * tr) * (emission * 0) whatever tr is), and a blocked lane stops being tested: none of this
+//     changes a bit;
+//   * the waiting rays' lowest entries live in LDS, [entry][word][lane].
+typedef double d4v __attribute__((ext_vector_type(4)));
+typedef const volatile d4v PTR_CONST* ConstD4;
+__device__ __forceinline__ void arrive(const d4v& q) { asm volatile("" ::"s"(q.x), "s"(q.y), "s"(q.z), "s"(q.w)); }
+// Correctly rounded float64 square root and reciprocal for operands in 2^-500 .. 2^500: the compiler's own sequences
+// (v_rsq_f64 / v_rcp_f64 + Newton steps in FMAs + a last residual correction) without the parts that only rescale operands
+// near the ends of the exponent range and patch zero / infinity (5-7 of 18 and 4 of 11 instructions).  Every call site asks
+// mid_range() for all its lanes first (two integer instructions on the high word) and takes the builtin otherwise, so the
+// results are the IEEE ones for every operand - which is what JavaScript's Math.sqrt and `/` return.
+__device__ __forceinline__ bool mid_range(double x)
+{
+    return (unsigned)__double2hiint(x) - 0x20B00000u < 0x3E800000u;      // exponent field in [1023 - 500, 1023 + 500): positive, normal
+}
+__device__ __forceinline__ double sqrt_mid(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+__device__ __forceinline__ double recip_mid(double s)
+{
+    double r = __builtin_amdgcn_rcp(s);
+    double e = __builtin_fma(-s, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-s, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double rem = __builtin_fma(-s, r, 1.0);        // (the quotient estimate of 1 / s is r itself)
+    return __builtin_fma(rem, r, r);
+}
+// normalize_v (Vector3.js:23-33) for all lanes of a wave
+__device__ __forceinline__ void normalize_w(V<double>& v)
+{
+    const double len2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    const bool ok = len2 > 0;
+    double inv;
+    if (ballot(ok & !mid_range(len2)) == 0ull) inv = recip_mid(sqrt_mid(len2));     // (sqrt of a mid-range value is mid-range)
+    else inv = 1.0 / __builtin_sqrt(len2);
+    if (ok) { v.x *= inv; v.y *= inv; v.z *= inv; }
+}
+// sqrt(x) for the lanes of `want` (the others: any value)
+__device__ __forceinline__ double sqrt_w(double x, bool want)
+{
+    if (ballot(want & !mid_range(x)) == 0ull) return sqrt_mid(x);
+    return __builtin_sqrt(x);
+}
+
+#ifndef PTR_EXT64_LDS_ENTRIES
+#define PTR_EXT64_LDS_ENTRIES 2
+#endif
+struct RayStack64 {
+    double* base;      // this lane's first double in LDS: 9 doubles per entry, 512 bytes apart
+    int* dbase;        // ... and its depth word
+    ExtRay<double> deep[PTR_EXT_MAX_DEPTH + 2 - PTR_EXT64_LDS_ENTRIES];
+    __device__ __forceinline__ void push(int at, const ExtRay<double>& c)
+    {
+        if (at < PTR_EXT64_LDS_ENTRIES) {
+            double* p = base + at * 576;
+            p[0] = c.o.x; p[64] = c.o.y; p[128] = c.o.z; p[192] = c.d.x; p[256] = c.d.y; p[320] = c.d.z;
+            p[384] = c.w.x; p[448] = c.w.y; p[512] = c.w.z;
+            dbase[at * 64] = c.depth;
+        } else {
+            deep[at - PTR_EXT64_LDS_ENTRIES] = c;
+        }
+    }
+    __device__ __forceinline__ ExtRay<double> pop(int at) const
+    {
+        if (at < PTR_EXT64_LDS_ENTRIES) {
+            const double* p = base + at * 576;
+            return ExtRay<double>{V<double>{p[0], p[64], p[128]}, V<double>{p[192], p[256], p[320]}, V<double>{p[384], p[448], p[512]},
+                                  dbase[at * 64]};
+        }
+        return deep[at - PTR_EXT64_LDS_ENTRIES];
+    }
+};
+
+__device__ V<double> trace_ext_f64w(RayStack64& stack, const unsigned char* block, const RenderArgs& a, V<double> o0, V<double> d0, int max_depth,
+                                    unsigned long long cand0)
+{
+    using T = double;
+    const ConstHeader hdr = (ConstHeader)(uintptr_t)block;
+    const ConstD4 g64v = (ConstD4)(uintptr_t)(block + hdr->off_g64);         // cx cy cz r2
+    const volatile double PTR_CONST* m64s = (const volatile double PTR_CONST*)(uintptr_t)(block + hdr->off_m64);   // sr sg sb er eg eb refl transp
+    const SphereG64* g64 = reinterpret_cast<const SphereG64*>(block + hdr->off_g64);      // per-lane gathers of the hit sphere
+    const SphereM64* m64 = reinterpret_cast<const SphereM64*>(block + hdr->off_m64);
+    const ConstI32 lights = (ConstI32)(uintptr_t)(block + hdr->off_lights);
+    const ConstF4 pairv0 = (ConstF4)(uintptr_t)(block + a.off_pairs);
+    const int n = a.n, nl = hdr->n_lights;
+    const V<T> bg{hdr->bg64[0], hdr->bg64[1], hdr->bg64[2]};
+
+    int top = 0;
+    ExtRay<T> r{o0, d0, V<T>{1, 1, 1}, 0};
+    bool have = true;
+    bool first = true;
+    V<T> acc{0, 0, 0};
+    while (have || top > 0) {
+        if (!have) r = stack.pop(--top);
+        have = false;
+        T tnear = T(PTR_INFINITY);
+        int e = -1;
+        if (n > 0) {
+            // Sphere.intersect (Sphere.js:15-33) + RayTracer.js:32-36 for one sphere and all lanes
+            auto test = [&](const d4v q, int i) {
+                const T lx = q.x - r.o.x, ly = q.y - r.o.y, lz = q.z - r.o.z;
+                const T tca = lx * r.d.x + ly * r.d.y + lz * r.d.z;
+                if (ballot(!(tca < 0)) == 0ull) return;                       // the sphere lies behind every ray of the wave (Sphere.js:18-19)
+                const T d2 = (lx * lx + ly * ly + lz * lz) - tca * tca;
+                const bool hit = !(tca < 0) & !(d2 > q.w);
+                if (ballot(hit) != 0ull) {
+                    const T thc = sqrt_w(q.w - d2, hit);
+                    T t0 = tca - thc;
+                    const T t1 = tca + thc;
+                    t0 = t0 < 0 ? t1 : t0;
+                    const bool nearer = hit & (t0 < tnear);
+                    tnear = nearer ? t0 : tnear;
+                    e = nearer ? i : e;
+                }
+            };
+            if (cand0 != ~0ull && __builtin_amdgcn_readfirstlane((int)first) != 0) {
+                for (unsigned long long c = cand0; c != 0ull; c &= c - 1ull) {
+                    const int i = __builtin_ctzll(c);
+                    const d4v q = g64v[i];
+                    arrive(q);
+                    test(q, i);
+                }
+            } else {
+                d4v A = g64v[0], B;
+                for (int i = 0;;) {
+                    arrive(A); B = g64v[i + 1 < n ? i + 1 : i]; test(A, i);
+                    if (++i >= n) break;
+                    arrive(B); A = g64v[i + 1 < n ? i + 1 : i]; test(B, i);
+                    if (++i >= n) break;
+                }
+            }
+        }
+        first = false;
+        if (e < 0) {
+            acc.x += r.w.x * bg.x; acc.y += r.w.y * bg.y; acc.z += r.w.z * bg.z;
+            continue;
+        }
+        const SphereM64 m = m64[e];
+        const SphereG64 ce = g64[e];
+        const V<T> em{m.er, m.eg, m.eb}, col{m.sr, m.sg, m.sb};
+        acc.x += r.w.x * em.x; acc.y += r.w.y * em.y; acc.z += r.w.z * em.z;
+        const V<T> P{r.o.x + r.d.x * tnear, r.o.y + r.d.y * tnear, r.o.z + r.d.z * tnear};
+        V<T> N{P.x - ce.cx, P.y - ce.cy, P.z - ce.cz};
+        normalize_w(N);
+        bool inside = false;
+        T dn = r.d.x * N.x + r.d.y * N.y + r.d.z * N.z;
+        if (dn > 0) { N.x = -N.x; N.y = -N.y; N.z = -N.z; inside = true; dn = -dn; }
+        const T transp = m.transp, refl = m.refl;
+        if ((transp > 0 || refl > 0) && r.depth < max_depth) {
+            const T facing = -dn;
+            const T f = 1 - facing;
+            const T fresnel = T(1) * T(0.1) + (f * f * f) * (T(1) - T(0.1));
+            const V<T> wsc{r.w.x * col.x, r.w.y * col.y, r.w.z * col.z};
+            if (transp > 0) {
+                const T eta = inside ? T(1.1) : T(1) / T(1.1);
+                const T cosi = -dn;
+                const T kk2 = 1 - eta * eta * (1 - cosi * cosi);
+                if (kk2 >= 0) {
+                    ExtRay<T> c;
+                    const T g = eta * cosi - sqrt_w(kk2, true);
+                    const T wt = (1 - fresnel) * transp;
+                    c.o = V<T>{P.x - N.x * T(PTR_BIAS), P.y - N.y * T(PTR_BIAS), P.z - N.z * T(PTR_BIAS)};
+                    c.d = V<T>{r.d.x * eta + N.x * g, r.d.y * eta + N.y * g, r.d.z * eta + N.z * g};
+                    c.w = V<T>{wsc.x * wt, wsc.y * wt, wsc.z * wt};
+                    normalize_w(c.d);
+                    c.depth = r.depth + 1;
+                    stack.push(top++, c);
+                }
+            }
+            const T two = 2 * dn;
+            ExtRay<T> c;
+            c.o = V<T>{P.x + N.x * T(PTR_BIAS), P.y + N.y * T(PTR_BIAS), P.z + N.z * T(PTR_BIAS)};
+            c.d = V<T>{r.d.x - N.x * two, r.d.y - N.y * two, r.d.z - N.z * two};
+            c.w = V<T>{wsc.x * fresnel, wsc.y * fresnel, wsc.z * fresnel};
+            normalize_w(c.d);
+            c.depth = r.depth + 1;
+            r = c;
+            have = true;
+        } else {
+            // the reference's direct lighting (RayTracer.js:60-91)
+            const V<T> so{P.x + N.x * T(PTR_BIAS), P.y + N.y * T(PTR_BIAS), P.z + N.z * T(PTR_BIAS)};
+            V<T> dif{0, 0, 0};
+            for (int kk = 0; kk < nl; kk++) {
+                const int i = lights[kk];
+                const d4v Cq = g64v[i];
+                const volatile double PTR_CONST* mi = m64s + 8 * i;                       // (three words of the light's record, not all eight: SGPRs)
+                const V<T> ei{mi[3], mi[4], mi[5]};
+                arrive(Cq);
+                V<T> L{Cq.x - P.x, Cq.y - P.y, Cq.z - P.z};
+                normalize_w(L);
+                T ratio = N.x * L.x + N.y * L.y + N.z * L.z;
+                // lanes whose term can be non-zero still need a verdict, as a lane mask
+                unsigned long long open_m = ballot(ratio > 0);
+                const unsigned long long asked_m = open_m;
+                if (open_m != 0ull) {
+                    const float Lx = (float)L.x, Ly = (float)L.y, Lz = (float)L.z;       // for the pre-filter alone
+                    const int prow = kk < PTR_MAX_PAIR_LIGHTS ? kk : (n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS);
+                    const ConstF4 pairs = pairv0 + (unsigned)prow * (unsigned)pair_stride(n);
+                    for (int j = 0; j < n && open_m != 0ull; j++) {
+                        if (j == i) continue;                                             // RayTracer.js:76
+                        const f4 pq = pairs[j];
+                        const d4v q = g64v[j];
+                        arrive(pq);
+                        const float c = fmaf(pq.z, Lz, fmaf(pq.y, Ly, pq.x * Lx));
+                        if ((ballot(fabsf(c) + 1e-5f >= pq.w) & open_m) == 0ull) continue;
+                        arrive(q);
+                        const T lx = q.x - so.x, ly = q.y - so.y, lz = q.z - so.z;
+                        const T tca = lx * L.x + ly * L.y + lz * L.z;
+                        if ((ballot(!(tca < 0)) & open_m) == 0ull) continue;              // behind every open lane's ray
+                        const T d2 = (lx * lx + ly * ly + lz * lz) - tca * tca;
+                        open_m &= ~ballot(!(tca < 0) & !(d2 > q.w));                      // any hit blocks; distance ignored (F7)
+                    }
+                }
+                const T tr = lane_of(asked_m & ~open_m) ? T(0) : T(1);
+                ratio = (ratio != ratio) ? ratio : (ratio > 0 ? ratio : T(0));           // Math.max(0, .)
+                dif.x += (col.x * tr) * (ei.x * ratio);
+                dif.y += (col.y * tr) * (ei.y * ratio);
+                dif.z += (col.z * tr) * (ei.z * ratio);
+            }
+            acc.x += r.w.x * dif.x; acc.y += r.w.y * dif.y; acc.z += r.w.z * dif.z;
+        }
+    }
+    return acc;
+}
+
+#ifndef PTR_EXT64_WAVES
+#define PTR_EXT64_WAVES 4
+#endif
+// ONE: one sample per pixel, a kernel of its own (the sample loop keeps the camera's 30 SGPRs alive through the whole ray tree:
+// with it the kernel spills scalar registers)
+template <bool ONE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTR_EXT64_WAVES, PTR_EXT64_WAVES))) render_ext_f64_kernel(RenderArgs a)
+{
+    const int lane = threadIdx.x;
+    const int x = blockIdx.x * 8 + (lane & 7), row = blockIdx.y * PTR_TILE_H + (lane >> 3), frame = blockIdx.z;
+    const unsigned char* block = a.scenes + (uint64_t)(a.first_frame + frame) * a.frame_stride;
+    __shared__ double ext_lds_d[PTR_EXT64_LDS_ENTRIES * 576];
+    __shared__ int ext_lds_i[PTR_EXT64_LDS_ENTRIES * 64];
+    RayStack64 st;
+    st.base = ext_lds_d + lane;
+    st.dbase = ext_lds_i + lane;
+    // the camera ray's candidates: the tile culling of render_ext_f32_body (float32 records, float32 margins: certain misses)
+    unsigned long long cand = ~0ull;
+    if (a.ext_cull_on && a.n <= 64) {
+        const CullRec* gcull = reinterpret_cast<const CullRec*>(block + a.off_cull);
+        const int li = lane < a.n ? lane : a.n;
+        const float4 g0 = *reinterpret_cast<const float4*>(&gcull[li].lx);
+        const float2 g1 = *reinterpret_cast<const float2*>(&gcull[li].re);
+        const float xc = fmaf((float)(blockIdx.x * 8 + 4), a.camf.sx, a.camf.ox);
+        const float yc = fmaf((float)(global_y(a, blockIdx.y * PTR_TILE_H) + PTR_TILE_H / 2), a.camf.sy, a.camf.oy);
+        V<float> dc{xc, yc, -1.0f};
+        if (a.cam.general) {
+            dc.x = fmaf(xc, a.camf.right[0], fmaf(yc, a.camf.up[0], a.camf.fwd[0]));
+            dc.y = fmaf(xc, a.camf.right[1], fmaf(yc, a.camf.up[1], a.camf.fwd[1]));
+            dc.z = fmaf(xc, a.camf.right[2], fmaf(yc, a.camf.up[2], a.camf.fwd[2]));
+        }
+        const float inv = rsq(fmaf(dc.z, dc.z, fmaf(dc.y, dc.y, dc.x * dc.x)));
+        const float bc = fmaf(g0.z, dc.z, fmaf(g0.y, dc.y, g0.x * dc.x)) * inv;
+        const float K = fmaf(a.ext_cull_cos, g0.w, -fmaf(a.ext_cull_sin, g1.x, g1.y));
+        cand = ballot(bc >= K) & (a.n >= 64 ? ~0ull : (1ull << a.n) - 1ull);
+    }
+    const int y = global_y(a, row);
+    if (x >= a.width || row >= a.scan_height) return;
+    const V<double> origin{a.cam.org[0], a.cam.org[1], a.cam.org[2]};
+    V<double> sum{0, 0, 0};
+    const int spp = ONE ? 1 : a.spp;
+    for (int s = 0; s < spp; s++) {
+        const V<double> d = ext_camera_dir<double>(a, x, y, s);
+        const V<double> c = trace_ext_f64w(st, block, a, origin, d, a.max_depth, cand);
+        sum.x += c.x; sum.y += c.y; sum.z += c.z;
+    }
+    ext_store<double>(a, frame, x, row, sum);
+}
+
+hipError_t launch_render_ext(const RenderArgs& a, int n_frames, bool f64, bool stats, bool spheres_only, bool lanewise, hipStream_t s)
 {
     dim3 grid((a.width + PTR_TILE_W - 1) / PTR_TILE_W, (a.scan_height + PTR_TILE_H - 1) / PTR_TILE_H, n_frames);
     if (stats) hipLaunchKernelGGL((render_ext_kernel<double, true>), grid, dim3(PTR_BLOCK), 0, s, a);
     // (one wave per workgroup, as below: 4-5 % faster than four; more waves per SIMD than the 4 its 120 VGPRs allow cost
     // spills: 5 waves +15 %, 6 waves +45 %)
+    else if (f64 && spheres_only && !lanewise)
+        hipLaunchKernelGGL(a.spp == 1 ? render_ext_f64_kernel<true> : render_ext_f64_kernel<false>, dim3((a.width + 7) / 8, grid.y, n_frames), dim3(64), 0, s, a);
     else if (f64) hipLaunchKernelGGL((render_ext_kernel<double, false>), dim3((a.width + 7) / 8, grid.y, n_frames), dim3(64), 0, s, a);
     else {
         // one wave per workgroup: the waves' run times differ by an order of magnitude (a tile on a transparent sphere

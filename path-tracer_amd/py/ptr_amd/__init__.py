@@ -20,6 +20,7 @@ FLAG_STATS = 0x0008
 FLAG_TIMING = 0x0010
 DEBUG_REASONS = 0x8000
 DEBUG_FORCE_MANY = 0x4000
+DEBUG_EXT_LANEWISE = 0x1000
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NO_SCENE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 

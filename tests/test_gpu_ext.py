@@ -289,3 +289,61 @@ def test_float32_form_with_turned_cameras_bands_and_strips(rdr, scenes):
                     assert np.array_equal(got, whole[part.global_rows(h)]), (cam, strip, part_no)
     finally:
         rdr.set_camera(None)
+
+
+def test_wave_level_float64_kernel_equals_the_lane_by_lane_one(rdr, scenes):
+    """Scenes of spheres take render_ext_f64_kernel (scalar sphere records, tile culling of the camera ray, the shadow loop's
+    pair table, square roots and reciprocals by the compiler's own Newton sequences without their range patches); the
+    lane-by-lane render_ext_kernel<double> is the specification written out per pixel (PTR_DEBUG_EXT_LANEWISE).  Same
+    bytes and the same float32 colours: moved, turned and wide cameras (the culling cone), bands that do not start on a tile
+    row, cyclic strips, several samples, scenes whose coordinates are scaled to both ends of what the culls' float32 margins
+    were built for."""
+    import math
+    import torch
+    LW = ptr_amd.DEBUG_EXT_LANEWISE
+    cams = [None,
+            dict(origin=(3.0, 1.5, 4.0)),
+            dict(origin=(-6.0, 2.0, -8.0), right=(math.cos(0.6), 0.0, math.sin(0.6)), up=(0.0, 1.0, 0.0),
+                 forward=(math.sin(0.6), 0.0, -math.cos(0.6))),
+            dict(origin=(0.0, 12.0, -14.0), right=(1.0, 0.0, 0.0), up=(0.0, math.cos(1.0), -math.sin(1.0)),
+                 forward=(0.0, -math.sin(1.0), -math.cos(1.0)), tan_half_fov=math.tan(math.radians(50))),
+            dict(origin=(0.0, 0.0, -20.0))]                          # the eye inside the transparent sphere
+    try:
+        for name in ("example1", "random_2", "random_5", "coincident", "inside_sphere"):
+            if name not in scenes:
+                continue
+            _load(rdr, scenes[name])
+            for cam in cams:
+                if cam is None:
+                    rdr.set_camera(None)
+                else:
+                    rdr.set_camera(**cam)
+                for (w, h, y0, rows, depth, spp) in ((333, 201, 0, 201, 5, 1), (256, 160, 13, 90, 3, 3), (97, 61, 0, 61, 7, 2)):
+                    a, af = rdr.render(w, h, y0, rows, flags=X, max_depth=depth, spp=spp, seed=9, want_f32=True)
+                    b, bf = rdr.render(w, h, y0, rows, flags=X | LW, max_depth=depth, spp=spp, seed=9, want_f32=True)
+                    assert np.array_equal(a, b), (name, cam, w, h, depth, spp)
+                    assert np.array_equal(af.view(np.uint32), bf.view(np.uint32)), (name, cam, w, h, depth, spp)
+        # scaled scenes: coordinates 1e-3 ... 1e4 times the example's
+        ex = orc.scene_to_soa(scenes["example1"]["elements"])
+        rdr.set_camera(None)
+        for k in (1e-3, 0.05, 30.0, 1e4):
+            s = ex.copy(); s[0:4] *= k
+            rdr.set_scene(s); rdr.set_background([0.7, 1.3, 0.2])
+            a = rdr.render(240, 135, flags=X, max_depth=5)
+            b = rdr.render(240, 135, flags=X | LW, max_depth=5)
+            assert np.array_equal(a, b), k
+        # cyclic strips (8 rows: whole tiles, culled; 5 rows: not)
+        _load(rdr, scenes["example1"])
+        w, h = 200, 120
+        whole = rdr.render(w, h, flags=X | LW, max_depth=4).reshape(h, w)
+        for strip in (8, 5):
+            for part_no in range(3):
+                part = ptr_amd.StripPart(3, part_no, strip)
+                rows = part.local_rows(h)
+                buf = torch.zeros((rows, w), dtype=torch.int32, device="cuda")
+                p = rdr.params(w, h, 0, rows, flags=X, max_depth=4)
+                rdr.render_strips_device(p, part, 0, 1, buf.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                assert np.array_equal(buf.cpu().numpy().view(np.uint32), whole[part.global_rows(h)]), (strip, part_no)
+    finally:
+        rdr.set_camera(None)

@@ -1,4 +1,4 @@
-"""Times the float32 extension kernel (PTR_MODE_F32_ONLY; PTR_AB_MODE=exact: the float64 one) on one MI355X and prints a hash of what it drew, so that two builds
+"""Times the float32 extension kernel (PTR_MODE_F32_ONLY; PTR_AB_MODE=exact / lanewise: the float64 ones) on one MI355X and prints a hash of what it drew, so that two builds
 of the library can be compared on one box:  python tools/ext_ab.py  (the library in the tree);
 PTR_AB_LIB=path/to/other.so python tools/ext_ab.py  (another build)."""
 import hashlib, json, os, sys, time
@@ -10,7 +10,8 @@ if os.environ.get("PTR_AB_LIB"):
 from ptr_amd import synthetic as syn
 from bench import example1_soa
 
-MODE = ptr_amd.MODE_EXACT_F64 if os.environ.get("PTR_AB_MODE") == "exact" else ptr_amd.MODE_F32_ONLY
+MODE = {"exact": ptr_amd.MODE_EXACT_F64, "lanewise": ptr_amd.MODE_EXACT_F64 | ptr_amd.DEBUG_EXT_LANEWISE}.get(os.environ.get("PTR_AB_MODE"), ptr_amd.MODE_F32_ONLY)
+# (PTR_AB_MODE=lanewise: the float64 form by the lane-by-lane kernel, PTR_DEBUG_EXT_LANEWISE; exact: the wave-level one)
 
 def run(r, name, w, h, depth, spp, frames, reps):
     out = torch.zeros((frames, h, w), dtype=torch.int32, device="cuda")
