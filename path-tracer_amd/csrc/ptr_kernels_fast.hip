@@ -627,16 +627,22 @@ render_fast_kernel(RenderArgs a)
                         const float hr = fmaf(mlo.x, s.ar, mhi.x), hg = fmaf(mlo.y, s.ag, mhi.y), hb = fmaf(mlo.z, s.ab, mhi.z);
                         // Math.round(v) = floor(v + 0.5); v + 0.5 is exact in float32 for 0.5 <= v < 256, and below 0.5 it can only
                         // round across 1.0 within the band that is re-traced anyway
-                        const float vr = fmin_raw(hr, 1.0f) * 255.0f, vg = fmin_raw(hg, 1.0f) * 255.0f, vb = fmin_raw(hb, 1.0f) * 255.0f;
                         if constexpr (!TOL) {
+                            const float vr = fmin_raw(hr, 1.0f) * 255.0f, vg = fmin_raw(hg, 1.0f) * 255.0f, vb = fmin_raw(hb, 1.0f) * 255.0f;
                             // |error of N.L| <= eN + eL (+ rounding of the dot and of the sums, 8 eps)
                             const float band = 255.0f * fmaf(mlo.w, s.werr, 4.0f * EPS * mhi.w) + 2e-5f;
                             const float qr = __builtin_amdgcn_fractf(vr) - 0.5f, qg = __builtin_amdgcn_fractf(vg) - 0.5f,
                                         qb = __builtin_amdgcn_fractf(vb) - 0.5f;
                             rdoubt[p] = fminf(fminf(fabsf(qr), fabsf(qg)), fabsf(qb)) - band;
                         }
-                        const uint32_t r8 = (uint32_t)(vr + 0.5f), g8 = (uint32_t)(vg + 0.5f), b8 = (uint32_t)(vb + 0.5f);
-                        packed[p] = (255u << 24) | (b8 << 16) | (g8 << 8) | r8;
+                        // v_cvt_pk_u8_f32: clamp to 0..255, round to nearest (ties to even), insert the byte - one instruction per
+                        // channel.  It differs from Math.round (ties up) on exact ties only, by one unit: inside the tolerant
+                        // form's promise (a float32 value within 0.9 of the float64 one still rounds to within one unit of the
+                        // reference's byte), and in the bytes-equal form a tie is a rounding doubt by definition (distance 0 from
+                        // the boundary) and is redone in float64.
+                        uint32_t pk = __builtin_amdgcn_cvt_pk_u8_f32(hr * 255.0f, 0u, 0xFF000000u);
+                        pk = __builtin_amdgcn_cvt_pk_u8_f32(hg * 255.0f, 1u, pk);
+                        packed[p] = __builtin_amdgcn_cvt_pk_u8_f32(hb * 255.0f, 2u, pk);
                         cr[p] = hr; cg[p] = hg; cb[p] = hb;
                     }
                 }
