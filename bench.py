@@ -578,7 +578,7 @@ def main():
         beyond = int((d8 > 1).sum().item())
         depth5 = {"workload": f"BASELINE.json configs[1]: example1 {WIDTH}x{HEIGHT}, depth 5, 1 spp, {frames_total} frames per step",
                   "mode": "default of the extension modes: the float64 specification bit for bit (0 pixels beyond 1/255 by construction)",
-                  **ext_entry(ms64, k64, PEAK_FP32_VALU_TFLOPS / 2, "render_ext_kernel<double>", "f64"),
+                  **ext_entry(ms64, k64, PEAK_FP32_VALU_TFLOPS / 2, "render_ext_f64_kernel", "f64"),
                   "rays_per_frame": rays5, "camera_rays": st5["primary"], "secondary_rays": st5["secondary"],
                   "shadow_rays": st5["shadow_rays"],
                   "f32_form": {**ext_entry(ms32, k32, PEAK_FP32_VALU_TFLOPS, "render_ext_f32_kernel", "f32"),
