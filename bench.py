@@ -43,17 +43,17 @@ STRIP = 8
 PEAK_FP32_VALU_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
 PEAK_HBM_GBPS = 8000.0
 # HBM traffic of the float32 kernel per pixel, from the PMC passes of this very command kept under profiles/
-# (r03_summary.md, kernel render_fast_kernel<2, false, 4, false, false>: WRITE_SIZE 2 092 060 KB and FETCH_SIZE 4 122.4 KB per
-# launch of 256 x 1920 x 1080 pixels; render_fast_kernel<1, false, 3, ...> of --mode exact: 2 305 220 KB and 5 725.1 KB; gfx950
+# (r03_summary.md, kernel render_fast_kernel<2, false, 4, false, false>: WRITE_SIZE 2 092 250 KB and FETCH_SIZE 4 110.0 KB per
+# launch of 256 x 1920 x 1080 pixels; render_fast_kernel<1, false, 3, ...> of --mode exact: 2 306 760 KB and 5 768.0 KB; gfx950
 # correction of the guide applied: FETCH_SIZE counts 64 B per 128-B request -> x 2).  Counters cannot be read from
 # inside this process, so the per-launch figure reported below is this profiled rate times the launch's pixels
 # (reported as "traffic", with "traffic_source" saying so).
-PROFILED_HBM_BYTES_PER_PIXEL = {"tolerant": (2092060.0 * 1024 + 2 * 4122.44 * 1024) / (256 * 1920 * 1080),
-                                "exact": (2305220.0 * 1024 + 2 * 5725.1 * 1024) / (256 * 1920 * 1080)}
+PROFILED_HBM_BYTES_PER_PIXEL = {"tolerant": (2092250.0 * 1024 + 2 * 4109.98 * 1024) / (256 * 1920 * 1080),
+                                "exact": (2306760.0 * 1024 + 2 * 5768.03 * 1024) / (256 * 1920 * 1080)}
 # ... and of one reprojection pass over the 1920 x 1080 x 4 cache on one GPU (same profile: rc_clear + rc_project + hipCUB's five
-# radix-sort kernels + rc_resolve; FETCH_SIZE 11.5 + 129 620 + 5 x 33 000.9 + 328 300 KB, x 2; WRITE_SIZE 24 840 + 209 808 +
-# 5 x 60 107.8 + 142 813 KB): 1.97 GB against 0.39 GB algorithmic
-PROFILED_RC_BYTES_PER_PASS = int((2 * (11.5 + 129620 + 5 * 33000.9 + 328300) + (24840 + 209808 + 5 * 60107.8 + 142813)) * 1024)
+# radix-sort kernels + rc_resolve; FETCH_SIZE 11.5 + 129 620 + 5 x 33 015.1 + 328 315 KB, x 2; WRITE_SIZE 24 840 + 209 808 +
+# 5 x 60 042.1 + 142 813 KB): 1.97 GB against 0.39 GB algorithmic
+PROFILED_RC_BYTES_PER_PASS = int((2 * (11.5 + 129620 + 5 * 33015.1 + 328315) + (24840 + 209808 + 5 * 60042.1 + 142813)) * 1024)
 
 
 def example1_soa():
