@@ -344,7 +344,23 @@ def main():
     # ---- N > 1: the library's communicator (RCCL), checked; torch.distributed is the channel for the id and the fallback
     gather_mode = None
     comm_stream = None
+    watchdog = None
     if world > 1:
+        # The library's exchange has its first multi-GPU runs in this very start-up phase.  An exception or a wrong frame
+        # falls back to torch.distributed below; a collective that never returns cannot be fallen back from, so a
+        # watchdog turns it into a quick, explained failure instead of a run that sits until the driver's limit.
+        # PTR_BENCH_GATHER=torch skips the library's exchange altogether.
+        import threading
+
+        def _stuck():
+            print(f"rank {rank}: the start-up phase of the multi-GPU exchange (communicator set-up + first checked gather) "
+                  f"did not finish within {WATCHDOG_S} s; set PTR_BENCH_GATHER=torch to run with torch.distributed's gather",
+                  file=sys.stderr, flush=True)
+            os._exit(3)
+        WATCHDOG_S = int(os.environ.get("PTR_BENCH_WATCHDOG_S", "300"))
+        watchdog = threading.Timer(WATCHDOG_S, _stuck)
+        watchdog.daemon = True
+        watchdog.start()
         ok = 1
         try:
             uid = torch.zeros(128, dtype=torch.uint8)
@@ -354,6 +370,8 @@ def main():
             dist.broadcast(uid, src=0)
             if backend != "nccl":
                 raise RuntimeError("rehearsal backend: ranks may share a GPU, which RCCL refuses")
+            if os.environ.get("PTR_BENCH_GATHER") == "torch":
+                raise RuntimeError("PTR_BENCH_GATHER=torch")
             rdr.comm_init_rank(bytes(uid.cpu().numpy().tobytes()), rank, world)
         except Exception as e:                   # noqa: BLE001 - whatever went wrong, every rank has to learn of it
             ok = 0
@@ -448,6 +466,7 @@ def main():
             dist.broadcast(flag, src=0)
         if int(flag.item()) != 1:
             raise SystemExit("gathered frame differs from the single-GPU frame")
+        watchdog.cancel()
 
     for _ in range(args.warmup):
         step()
@@ -482,6 +501,75 @@ def main():
     fence()
     main_ms = float(np.mean([k[0] for k in kms]))
     retrace_ms = float(np.mean([k[1] for k in kms]))
+
+    out = None
+    if rank == 0:
+        share = local_rows / HEIGHT                      # fraction of every frame this rank renders
+        total_rays = rays_per_frame * frames_total       # all ranks together, per step
+        value = total_rays * args.steps / elapsed / 1e6
+        launch_flops = flops_per_frame * frames_total * share
+        launch_bytes = 4.0 * WIDTH * local_rows * frames_total
+        achieved = launch_flops / (main_ms * 1e-3) / 1e12
+        out = {
+            "metric": "Mrays/sec (primary+secondary) at 1080p",
+            "value": round(value, 1), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ("f32 (discontinuous doubts re-traced in f64; every channel of every pixel within 1/255 of the f64 reference: "
+                      "PTR_MODE_TOLERANT)") if head_flags else
+                     "f32 (uncertain pixels re-traced in f64; output bytes equal the f64 reference)",
+            "timed_region_s": round(elapsed, 4),
+            "data": "synthetic",
+            "config": {"workload": f"example1 scene (7 spheres, 2 lights) {WIDTH}x{HEIGHT}, 1 spp, reference "
+                                   f"semantics (depth 0), {args.frames} frames per GPU per step, "
+                                   + ("tolerant hybrid mode (<= 1/255)" if head_flags else "hybrid mode (reference bytes)"),
+                       "frames_per_step": frames_total, "rays_per_frame": rays_per_frame,
+                       "parallelism": "1 GPU" if world == 1 else
+                       f"{world} ranks, cyclic {STRIP}-row strips, RCCL gather to rank 0 in the timed region, "
+                       f"overlapped with the next step's render"},
+            "Mpixels_per_s": round(WIDTH * HEIGHT * frames_total * args.steps / elapsed / 1e6, 1),
+            "roofline": {"bound": "valu", "kernel": "render_fast_kernel<tolerant>" if head_flags else "render_fast_kernel<hybrid>",
+                         "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
+                         "frac_step": round(launch_flops / (elapsed / args.steps) / 1e12 / PEAK_FP32_VALU_TFLOPS, 4),
+                         "traffic": int(PROFILED_HBM_BYTES_PER_PIXEL["tolerant" if head_flags else "exact"] * WIDTH * local_rows * frames_total),
+                         "traffic_source": "not measured in this run: PMC bytes per pixel of the profiled run of this command "
+                                           "(profiles/r03_summary.md, WRITE_SIZE + 2 x FETCH_SIZE passes) x pixels of this "
+                                           "launch; algorithmic bytes = 4 per pixel",
+                         "kernel_ms": round(main_ms, 4), "retrace_kernel_ms": round(retrace_ms, 4),
+                         "algorithmic_flops_per_launch": int(launch_flops),
+                         "hbm_frac": round(launch_bytes / (main_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                         "note": "FP32 vector-ALU bound (SURVEY.md 8d): no dense contraction, 4 B/pixel of HBM "
+                                 "traffic; achieved = algorithmic FLOPs of the reference's control flow / the float32 kernel's "
+                                 "own time; frac_step = the same FLOPs / the whole timed step (float32 kernel + float64 "
+                                 "re-trace + gaps), i.e. what the path delivers with the reference's bytes"},
+        }
+        if render_only is not None:
+            out["phases"] = {
+                "render_only_ms_per_step": round(render_only / args.steps * 1e3, 4),
+                "render_only_Mrays_per_s": round(total_rays * args.steps / render_only / 1e6, 1),
+                "gather_not_hidden_ms_per_step": round((elapsed - render_only) / args.steps * 1e3, 4),
+                "gathered_bytes_per_step_into_rank0": int(4 * WIDTH * HEIGHT * frames_total * (world - 1) / world),
+                "gather": gather_mode, "gather_overlapped_with_next_render": True,
+                "rank0_inbound_link_bound_ms_per_step": round(4 * WIDTH * HEIGHT * frames_total / world / 64e9 * 1e3, 3),
+                "note": "at 1 sample per pixel one GPU produces 0.8 TB/s of pixels; every peer's share of a step crosses ONE xGMI "
+                        "link into rank 0 (about 64 GB/s in one direction): the figure above is that link's time for a step, "
+                        "which no overlap can hide once it exceeds the render time (DESIGN.md section 6)"}
+
+    # ---- N > 1: what follows (configs[3], the sharded reprojection pass) are more first runs of library collectives.  If one of
+    # them never returns, the headline line above is printed as it stands and the process ends, instead of nothing at all.
+    extras_watchdog = None
+    if world > 1:
+        def _extras_stuck():
+            if rank == 0:
+                out["note_extras"] = ("config3_4k_256spp / config5_rc_reprojection did not finish within "
+                                      f"{EXTRAS_S} s and were cut off; the headline figures are complete")
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        EXTRAS_S = int(os.environ.get("PTR_BENCH_EXTRAS_S", "240"))
+        extras_watchdog = threading.Timer(EXTRAS_S + (0 if rank == 0 else 5), _extras_stuck)
+        extras_watchdog.daemon = True
+        extras_watchdog.start()
 
     # ---- N = 1: the other precision mode on the same workload, timed the same way; the latency of ONE frame per launch
     other = None
@@ -670,59 +758,6 @@ def main():
                                        bool(gather_mode == "library"), stream, max(5, min(args.steps, 20)))
 
     if rank == 0:
-        share = local_rows / HEIGHT                      # fraction of every frame this rank renders
-        total_rays = rays_per_frame * frames_total       # all ranks together, per step
-        value = total_rays * args.steps / elapsed / 1e6
-        launch_flops = flops_per_frame * frames_total * share
-        launch_bytes = 4.0 * WIDTH * local_rows * frames_total
-        achieved = launch_flops / (main_ms * 1e-3) / 1e12
-        out = {
-            "metric": "Mrays/sec (primary+secondary) at 1080p",
-            "value": round(value, 1), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (discontinuous doubts re-traced in f64; every channel of every pixel within 1/255 of the f64 reference: "
-                      "PTR_MODE_TOLERANT)") if head_flags else
-                     "f32 (uncertain pixels re-traced in f64; output bytes equal the f64 reference)",
-            "timed_region_s": round(elapsed, 4),
-            "data": "synthetic",
-            "config": {"workload": f"example1 scene (7 spheres, 2 lights) {WIDTH}x{HEIGHT}, 1 spp, reference "
-                                   f"semantics (depth 0), {args.frames} frames per GPU per step, "
-                                   + ("tolerant hybrid mode (<= 1/255)" if head_flags else "hybrid mode (reference bytes)"),
-                       "frames_per_step": frames_total, "rays_per_frame": rays_per_frame,
-                       "parallelism": "1 GPU" if world == 1 else
-                       f"{world} ranks, cyclic {STRIP}-row strips, RCCL gather to rank 0 in the timed region, "
-                       f"overlapped with the next step's render"},
-            "Mpixels_per_s": round(WIDTH * HEIGHT * frames_total * args.steps / elapsed / 1e6, 1),
-            "roofline": {"bound": "valu", "kernel": "render_fast_kernel<tolerant>" if head_flags else "render_fast_kernel<hybrid>",
-                         "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
-                         "frac_step": round(launch_flops / (elapsed / args.steps) / 1e12 / PEAK_FP32_VALU_TFLOPS, 4),
-                         "traffic": int(PROFILED_HBM_BYTES_PER_PIXEL["tolerant" if head_flags else "exact"] * WIDTH * local_rows * frames_total),
-                         "traffic_source": "not measured in this run: PMC bytes per pixel of the profiled run of this command "
-                                           "(profiles/r03_summary.md, WRITE_SIZE + 2 x FETCH_SIZE passes) x pixels of this "
-                                           "launch; algorithmic bytes = 4 per pixel",
-                         "kernel_ms": round(main_ms, 4), "retrace_kernel_ms": round(retrace_ms, 4),
-                         "algorithmic_flops_per_launch": int(launch_flops),
-                         "hbm_frac": round(launch_bytes / (main_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
-                         "note": "FP32 vector-ALU bound (SURVEY.md 8d): no dense contraction, 4 B/pixel of HBM "
-                                 "traffic; achieved = algorithmic FLOPs of the reference's control flow / the float32 kernel's "
-                                 "own time; frac_step = the same FLOPs / the whole timed step (float32 kernel + float64 "
-                                 "re-trace + gaps), i.e. what the path delivers with the reference's bytes"},
-        }
-        if render_only is not None:
-            out["phases"] = {
-                "render_only_ms_per_step": round(render_only / args.steps * 1e3, 4),
-                "render_only_Mrays_per_s": round(total_rays * args.steps / render_only / 1e6, 1),
-                "gather_not_hidden_ms_per_step": round((elapsed - render_only) / args.steps * 1e3, 4),
-                "gathered_bytes_per_step_into_rank0": int(4 * WIDTH * HEIGHT * frames_total * (world - 1) / world),
-                "gather": gather_mode, "gather_overlapped_with_next_render": True,
-                "rank0_inbound_link_bound_ms_per_step": round(4 * WIDTH * HEIGHT * frames_total / world / 64e9 * 1e3, 3),
-                "note": "at 1 sample per pixel one GPU produces 0.8 TB/s of pixels; every peer's share of a step crosses ONE xGMI "
-                        "link into rank 0 (about 64 GB/s in one direction): the figure above is that link's time for a step, "
-                        "which no overlap can hide once it exceeds the render time (DESIGN.md section 6)"}
-            if config3 is not None:
-                out["config3_4k_256spp"] = config3
         if other is not None:
             o_val = total_rays / other["ms_per_step"] / 1e3
             o_ach = launch_flops / (other["main_ms"] * 1e-3) / 1e12
@@ -736,7 +771,7 @@ def main():
                              "kernel_ms": round(other["main_ms"], 4), "retrace_kernel_ms": round(other["retrace_ms"], 4)}}
         if per_launch is not None:
             out["per_launch"] = per_launch
-        if config3 is not None and world == 1:
+        if config3 is not None:
             out["config3_4k_256spp"] = config3
         if depth5 is not None:
             out["extension_depth5"] = depth5
@@ -745,6 +780,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(soa, bg)
             out["cpu_baseline_js"] = cpu_baseline_js()
+    if extras_watchdog is not None:
+        extras_watchdog.cancel()
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
