@@ -50,10 +50,10 @@ extern "C" {
  * than 1/255) are re-traced in float64.  A pixel whose decisions are all certain keeps its float32 colour when the summed
  * error bounds of its N.L terms keep that colour within one 8-bit unit of the float64 one (re-traced otherwise), so every
  * channel of every pixel is within 1 of the reference's byte; what the default pays for equal bytes - the 8-bit rounding
- * doubt, its error sums and the shading-only re-do - is not paid.  It changes the few-sphere kernel of the reference
- * semantics only (max_depth 0, spp 1, no planes, no Phong terms, at most 12 spheres); everywhere else the flag is accepted
- * and the call renders as the default does (more spheres: the default hybrid form, bytes equal; an extension mode: float64,
- * the specification bit for bit), which meets the same bar.                                                                 */
+ * doubt, its error sums and the shading-only re-do - is not paid.  Reference semantics only (max_depth 0, spp 1, no planes,
+ * no Phong terms).  With more than 12 spheres (the many-sphere kernel) the rounding doubt alone is traded for one test of the
+ * colour's error bound (0.9 units), the other doubts and both kinds of re-do stay.  With an extension mode the flag is accepted
+ * and the call renders as the default does (float64, the specification bit for bit), which meets the same bar.               */
 #define PTR_MODE_TOLERANT     0x0020u
 /* Accumulate work counters (ptr_get_stats) during this call; slower, not for timing.        */
 #define PTR_FLAG_STATS        0x0008u

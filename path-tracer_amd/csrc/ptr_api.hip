@@ -589,7 +589,8 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
         c->hybrid_calls++;
         HIP_TRY(c, hipMemsetAsync(words + WORDS_STATS, 0, 256, s));
     }
-    // (PTR_MODE_TOLERANT: the few-sphere kernel has a form of its own; the many-sphere kernel keeps every doubt)
+    // (PTR_MODE_TOLERANT: the few-sphere kernel has a form of its own; the many-sphere kernel reads the flag and trades its
+    // rounding doubt for one test of the colour's error bound, its queue keeps both kinds)
     hipError_t e = many ? launch_render_many(a, n_frames, true, s)
                         : launch_render_fast(a, n_frames, (p->flags & PTR_MODE_TOLERANT) ? 2 : 1, s);
     if (e == hipSuccess && timing) e = hipEventRecord(c->ev[1], s);

@@ -100,6 +100,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_many_kernel(RenderArgs a)
 {
     constexpr int PPL = PTR_MANY_PPL, NP = PPL / 2;      // pixel p = 2 * pair + component
     constexpr bool BOUNDS = HYBRID || DBG;                // the error-bound arithmetic has a consumer
+    const bool tolerant = HYBRID && (a.flags & 0x0020u) != 0u;   // PTR_MODE_TOLERANT (include/ptr.h)
     __shared__ f4 tile[SMALL ? 1 : PTR_MANY_CHUNK];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -535,7 +536,10 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_many_kernel(RenderArgs a)
             // of the products and sums: 10 eps, + the float32 emission: 4 eps)
             const f2 band = 255.0f * pk_fma(f2{m0.scmax, m1.scmax} * wsum[q], eN[q] + eLmax[q] + splat(10.0f * EPS),
                                             (4.0f * EPS) * f2{m0.emax, m1.emax}) + splat(2e-5f);
-            const f2 nearest = min2(min2(abs2(qr - splat(0.5f)), abs2(qg - splat(0.5f))), abs2(qb - splat(0.5f)));
+            // bytes-equal form: a channel within `band` of a rounding boundary is redone.  Tolerant form (PTR_MODE_TOLERANT, a
+            // wave-uniform flag: one select per pixel pair): the rounding may fall either way, the pixel is redone only when
+            // the colour itself may be off by more than 0.9 units - then the rounded bytes could differ by more than one.
+            const f2 nearest = tolerant ? splat(0.9f) : min2(min2(abs2(qr - splat(0.5f)), abs2(qg - splat(0.5f))), abs2(qb - splat(0.5f)));
             fl[2 * q] |= flag<DBG>((nearest.x <= band.x) & valid[2 * q], FL_SHADE, WHY_ROUND);
             fl[2 * q + 1] |= flag<DBG>((nearest.y <= band.y) & valid[2 * q + 1], FL_SHADE, WHY_ROUND);
         }

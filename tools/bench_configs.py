@@ -66,6 +66,7 @@ def main():
     X, F = ptr_amd.MODE_EXACT_F64, ptr_amd.MODE_F32_ONLY
     if "c2" in which:
         run(r, "C2 example1 depth0 hybrid", syn.example1(), 1920, 1080, 0, 0, 1)
+        run(r, "C2 example1 depth0 tolerant", syn.example1(), 1920, 1080, ptr_amd.MODE_TOLERANT, 0, 1)
         run(r, "C2 example1 depth5 f64", syn.example1(), 1920, 1080, X, 5, 1)
         run(r, "C2 example1 depth5 f32", syn.example1(), 1920, 1080, F, 5, 1)
     if "c3" in which:
@@ -75,6 +76,7 @@ def main():
     if "c5" in which:
         big = syn.many_spheres()
         run(r, "C5 10k depth0 hybrid", big, 1920, 1080, 0, 0, 1)
+        run(r, "C5 10k depth0 tolerant", big, 1920, 1080, ptr_amd.MODE_TOLERANT, 0, 1)
         run(r, "C5 10k depth0 f32", big, 1920, 1080, F, 0, 1)
         run(r, "C5 10k depth0 f64", big, 1920, 1080, X, 0, 1, reps=1)
         run(r, "C5 10k depth1 f32", big, 1920, 1080, F, 1, 1, reps=1)
