@@ -207,6 +207,32 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
         for (int j = 0; j < pair_stride(n); j++) pairs[row * (size_t)pair_stride(n) + (size_t)j] = PairQ{0, 0, 0, -1.0f};
     }
     {
+        // The float64 bounce loop must reproduce the specification's float64 arithmetic bit for bit, its rounding included.
+        // A culled (light, occluder) pair is a miss in exact arithmetic: the shadow ray's line stays farther than
+        // r + 1e-6 (r + D) from the occluder's centre (`reach` above minus the bias), i.e. d2 - r^2 > 2e-6 r (r + D).  The
+        // float64 test computes d2 = |l|^2 - tca^2 with an error of up to 14 eps |l|^2 (eps = 2^-53): for a far origin
+        // (a hit point on a plane, anywhere) that exceeds the margin, the test's outcome is rounding noise, and the cull would
+        // differ from it.  So the cull is allowed only while 8 x 14 eps |l|^2 < 2e-6 r (r + D) for every pair, with
+        // |l| <= |origin - camera| + the largest |centre - camera|: one number per frame.
+        double worst = INFINITY, far = 0.0;
+        for (int j = 0; j < n; j++) far = std::fmax(far, (double)p32[j].lnorm);
+        for (int k = 0; k < nl && k < PTR_MAX_PAIR_LIGHTS; k++)
+            for (int j = 0; j < n; j++) {
+                if (!(pairs[(size_t)k * (size_t)pair_stride(n) + (size_t)j].thr > 0.0f)) continue;       // never culled anyway
+                const int i = lights[k];
+                const double ax = pl(0, j) - pl(0, i), ay = pl(1, j) - pl(1, i), az = pl(2, j) - pl(2, i);
+                const double r = std::fabs(pl(3, j));
+                worst = std::fmin(worst, r * (r + std::sqrt(ax * ax + ay * ay + az * az)));
+            }
+        const double ll_safe = 2.0e-6 * worst / (8.0 * 14.0 * 1.1102230246251565e-16);
+        const double smax = std::sqrt(ll_safe) - far * 1.000001;
+        h->pair_smax2 = (std::isfinite(smax) && smax > 0) ? (float)(smax * smax * 0.999) : (worst == INFINITY ? 3.0e38f : -1.0f);
+        // hit points on spheres: |P + bias N - camera| <= |centre - camera| + r + bias
+        double reach_max = 0.0;
+        for (int j = 0; j < n; j++) reach_max = std::fmax(reach_max, (double)p32[j].lnorm * 1.000001 + std::fabs(pl(3, j)) + 2.0e-4);
+        h->pair_always = (double)h->pair_smax2 >= reach_max * reach_max * 1.001 ? 1u : 0u;
+    }
+    {
         float* x4 = reinterpret_cast<float*>(dst + L.off_x4);
         const size_t padded = align_up((size_t)n, 4) + 4;
         for (size_t i = 0; i < padded; i++) {

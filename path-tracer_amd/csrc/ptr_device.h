@@ -47,13 +47,17 @@ struct alignas(16) FrameHeader {          // 128 bytes
     float    tol_thr;                     // PTR_MODE_TOLERANT: a hit pixel whose summed error bounds of N.L (|error of N| + the sum
                                           //   over the lights of |error of L|) exceed this is re-traced; below it the float32
                                           //   colour is within 0.9 / 255 of the float64 one (host: build_frame_block)
-    uint32_t off_g64, off_m64, off_p32, off_m32, off_lights, off_pad;   // byte offsets in block
+    uint32_t off_g64, off_m64, off_p32, off_m32, off_lights;             // byte offsets in block
+    uint32_t pair_always;                 // 1: every hit point ON A SPHERE of this scene is within sqrt(pair_smax2) of the camera (scenes without
+                                          //   planes need no per-ray test)
     uint32_t self_skip;                   // 1: coordinates are small enough for the "own sphere never shadows" proof
     // planes and Phong terms (extension modes only, include/ptr.h "planes and Phong"); elements = spheres, then planes
     uint32_t n_planes;
     uint32_t has_phong;                   // 1: phong64 / phong32 hold ks[n + n_planes] then exponent[n + n_planes]
     uint32_t off_pl64, off_plm64, off_pl32, off_plm32, off_ph64, off_ph32;
-    uint32_t pad1[1];
+    float    pair_smax2;                  // float64 bounce loop: the shadow pre-filter (PairQ) may only cull for a shadow ray whose origin lies
+                                          //   within sqrt(this) of the camera: farther out the float64 test itself rounds by more than the
+                                          //   margin the pre-filter leaves, and the kernel has to reproduce that rounding (< 0: never)
 };
 static_assert(sizeof(FrameHeader) == 128, "FrameHeader layout");
 

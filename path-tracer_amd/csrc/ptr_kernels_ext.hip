@@ -729,6 +729,9 @@ __device__ __forceinline__ void arrive(const d4v& q) { asm volatile("" ::"s"(q.x
 // results are the IEEE ones for every operand - which is what JavaScript's Math.sqrt and `/` return.
 __device__ __forceinline__ bool mid_range(double x)
 {
+#ifdef PTR_EXT64_NO_MID
+    return false;
+#endif
     return (unsigned)__double2hiint(x) - 0x20B00000u < 0x3E800000u;      // exponent field in [1023 - 500, 1023 + 500): positive, normal
 }
 __device__ __forceinline__ double sqrt_mid(double x)
@@ -799,10 +802,13 @@ struct RayStack64 {
     }
 };
 
+// GEN: the scene may have planes (elements n, n + 1, ...) and Phong terms; a kernel of its own, as in the float32 form
+template <bool GEN>
 __device__ V<double> trace_ext_f64w(RayStack64& stack, const unsigned char* block, const RenderArgs& a, V<double> o0, V<double> d0, int max_depth,
                                     unsigned long long cand0)
 {
     using T = double;
+    typedef const volatile double PTR_CONST* ConstD;
     const ConstHeader hdr = (ConstHeader)(uintptr_t)block;
     const ConstD4 g64v = (ConstD4)(uintptr_t)(block + hdr->off_g64);         // cx cy cz r2
     const volatile double PTR_CONST* m64s = (const volatile double PTR_CONST*)(uintptr_t)(block + hdr->off_m64);   // sr sg sb er eg eb refl transp
@@ -812,6 +818,15 @@ __device__ V<double> trace_ext_f64w(RayStack64& stack, const unsigned char* bloc
     const ConstF4 pairv0 = (ConstF4)(uintptr_t)(block + a.off_pairs);
     const int n = a.n, nl = hdr->n_lights;
     const V<T> bg{hdr->bg64[0], hdr->bg64[1], hdr->bg64[2]};
+    [[maybe_unused]] const bool pair_always = hdr->pair_always != 0u;
+    // planes: px py pz nx ny nz (PlaneG64), their materials (SphereM64's layout), the Phong terms (ks per element, then the exponents)
+    const int np = GEN ? (int)hdr->n_planes : 0;
+    const bool phong = GEN && hdr->has_phong != 0u;
+    const ConstD pl64s = (ConstD)(uintptr_t)(block + (GEN ? hdr->off_pl64 : 0u));
+    const ConstD plm64s = (ConstD)(uintptr_t)(block + (GEN ? hdr->off_plm64 : 0u));
+    const PlaneG64* pl64 = reinterpret_cast<const PlaneG64*>(block + (GEN ? hdr->off_pl64 : 0u));       // per-lane gathers
+    const SphereM64* plm64 = reinterpret_cast<const SphereM64*>(block + (GEN ? hdr->off_plm64 : 0u));
+    const double* ph64 = reinterpret_cast<const double*>(block + (GEN ? hdr->off_ph64 : 0u));
 
     int top = 0;
     ExtRay<T> r{o0, d0, V<T>{1, 1, 1}, 0};
@@ -858,18 +873,38 @@ __device__ V<double> trace_ext_f64w(RayStack64& stack, const unsigned char* bloc
                 }
             }
         }
+        if constexpr (GEN) {
+            // Plane.intersect of the specification: denom = d.n; 0 -> miss; t = ((p - o).n) / denom; t < 0 -> miss
+            for (int q = 0; q < np; q++) {
+                const ConstD pl = pl64s + 6 * q;
+                const T ppx = pl[0], ppy = pl[1], ppz = pl[2], pnx = pl[3], pny = pl[4], pnz = pl[5];
+                const T denom = r.d.x * pnx + r.d.y * pny + r.d.z * pnz;
+                const T t = ((ppx - r.o.x) * pnx + (ppy - r.o.y) * pny + (ppz - r.o.z) * pnz) / denom;
+                const bool nearer = !(denom == 0) & !(t < 0) & (t < tnear);
+                tnear = nearer ? t : tnear;
+                e = nearer ? n + q : e;
+            }
+        }
         first = false;
         if (e < 0) {
             acc.x += r.w.x * bg.x; acc.y += r.w.y * bg.y; acc.z += r.w.z * bg.z;
             continue;
         }
-        const SphereM64 m = m64[e];
-        const SphereG64 ce = g64[e];
+        const bool on_plane = GEN && e >= n;
+        SphereM64 m;
+        V<T> N;
+        if (on_plane) m = plm64[e - n]; else m = m64[e];
         const V<T> em{m.er, m.eg, m.eb}, col{m.sr, m.sg, m.sb};
         acc.x += r.w.x * em.x; acc.y += r.w.y * em.y; acc.z += r.w.z * em.z;
         const V<T> P{r.o.x + r.d.x * tnear, r.o.y + r.d.y * tnear, r.o.z + r.d.z * tnear};
-        V<T> N{P.x - ce.cx, P.y - ce.cy, P.z - ce.cz};
-        normalize_w(N);
+        if (on_plane) {
+            const PlaneG64 g = pl64[e - n];
+            N = V<T>{g.nx, g.ny, g.nz};                             // a plane's normal is the unit vector it was given
+        } else {
+            const SphereG64 ce = g64[e];
+            N = V<T>{P.x - ce.cx, P.y - ce.cy, P.z - ce.cz};
+            normalize_w(N);
+        }
         bool inside = false;
         T dn = r.d.x * N.x + r.d.y * N.y + r.d.z * N.z;
         if (dn > 0) { N.x = -N.x; N.y = -N.y; N.z = -N.z; inside = true; dn = -dn; }
@@ -908,21 +943,64 @@ __device__ V<double> trace_ext_f64w(RayStack64& stack, const unsigned char* bloc
             // the reference's direct lighting (RayTracer.js:60-91)
             const V<T> so{P.x + N.x * T(PTR_BIAS), P.y + N.y * T(PTR_BIAS), P.z + N.z * T(PTR_BIAS)};
             V<T> dif{0, 0, 0};
-            for (int kk = 0; kk < nl; kk++) {
-                const int i = lights[kk];
-                const d4v Cq = g64v[i];
-                const volatile double PTR_CONST* mi = m64s + 8 * i;                       // (three words of the light's record, not all eight: SGPRs)
-                const V<T> ei{mi[3], mi[4], mi[5]};
-                arrive(Cq);
-                V<T> L{Cq.x - P.x, Cq.y - P.y, Cq.z - P.z};
+            // The pair table may only cull for origins near enough to the camera: farther out the float64 test below rounds
+            // by more than the margin the table leaves, and that rounding is part of the specification's result
+            // (FrameHeader::pair_smax2; hit points on a plane can lie anywhere).
+            // Scenes of spheres alone: hit points lie on the spheres, the host has decided for the whole frame (pair_always).
+            [[maybe_unused]] unsigned long long pair_ok_m = ~0ull;
+            if constexpr (GEN) {
+                const T sox = so.x - a.cam.org[0], soy = so.y - a.cam.org[1], soz = so.z - a.cam.org[2];
+                pair_ok_m = ballot((float)(sox * sox + soy * soy + soz * soz) <= hdr->pair_smax2);
+            }
+            // Phong term of the specification: ks * max(0, R.L)^exponent per light, R = d - 2 (d.N) N
+            T ks = 0;
+            V<T> Rv{0, 0, 0};
+            unsigned pexp = 1u;
+            if constexpr (GEN) if (phong) {
+                ks = ph64[e];
+                pexp = (unsigned)ph64[n + np + e];
+                const T two_dn = 2 * dn;
+                Rv = V<T>{r.d.x - N.x * two_dn, r.d.y - N.y * two_dn, r.d.z - N.z * two_dn};
+            }
+            // lights: the emissive spheres in scene order (the host's list), then the emissive planes
+            for (int kk = 0; kk < nl + np; kk++) {
+                int i;
+                V<T> Ci, ei;
+                if (!GEN || kk < nl) {
+                    i = lights[kk];
+                    const d4v Cq = g64v[i];
+                    const ConstD mi = m64s + 8 * i;                                       // (three words of the light's record, not all eight: SGPRs)
+                    ei = V<T>{mi[3], mi[4], mi[5]};
+                    arrive(Cq);
+                    Ci = V<T>{Cq.x, Cq.y, Cq.z};
+                } else {
+                    i = n + (kk - nl);
+                    const ConstD mi = plm64s + 8 * (kk - nl);
+                    ei = V<T>{mi[3], mi[4], mi[5]};
+                    if (!(ei.x > 0 || ei.y > 0 || ei.z > 0)) continue;
+                    const ConstD pl = pl64s + 6 * (kk - nl);
+                    Ci = V<T>{pl[0], pl[1], pl[2]};
+                }
+                V<T> L{Ci.x - P.x, Ci.y - P.y, Ci.z - P.z};
+                [[maybe_unused]] const T len2 = L.x * L.x + L.y * L.y + L.z * L.z;         // a plane only blocks in front of the light
                 normalize_w(L);
                 T ratio = N.x * L.x + N.y * L.y + N.z * L.z;
-                // lanes whose term can be non-zero still need a verdict, as a lane mask
-                unsigned long long open_m = ballot(ratio > 0);
+                [[maybe_unused]] T sp = 0;
+                bool shines = false;                                                      // the lane has a Phong term that can be non-zero
+                if constexpr (GEN) {
+                    if (ballot(ks > 0) != 0ull) {
+                        sp = Rv.x * L.x + Rv.y * L.y + Rv.z * L.z;
+                        shines = (ks > 0) & (!(sp <= 0) | (pexp == 0u));
+                    }
+                }
+                // lanes whose terms can be non-zero still need a verdict, as a lane mask
+                unsigned long long open_m = ballot((ratio > 0) | shines);
                 const unsigned long long asked_m = open_m;
                 if (open_m != 0ull) {
                     const float Lx = (float)L.x, Ly = (float)L.y, Lz = (float)L.z;       // for the pre-filter alone
-                    const int prow = kk < PTR_MAX_PAIR_LIGHTS ? kk : (n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS);
+                    const bool cull_ok = GEN ? (open_m & ~pair_ok_m) == 0ull : pair_always;
+                    const int norow = n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS;  // (the never-cull row: plane lights, lights past the table)
+                    const int prow = (kk < nl && kk < PTR_MAX_PAIR_LIGHTS) ? kk : norow;
                     const ConstF4 pairs = pairv0 + (unsigned)prow * (unsigned)pair_stride(n);
                     for (int j = 0; j < n && open_m != 0ull; j++) {
                         if (j == i) continue;                                             // RayTracer.js:76
@@ -930,7 +1008,9 @@ __device__ V<double> trace_ext_f64w(RayStack64& stack, const unsigned char* bloc
                         const d4v q = g64v[j];
                         arrive(pq);
                         const float c = fmaf(pq.z, Lz, fmaf(pq.y, Ly, pq.x * Lx));
-                        if ((ballot(fabsf(c) + 1e-5f >= pq.w) & open_m) == 0ull) continue;
+#ifndef PTR_EXT64_NO_PAIRCULL
+                        if (cull_ok && (ballot(fabsf(c) + 1e-5f >= pq.w) & open_m) == 0ull) continue;
+#endif
                         arrive(q);
                         const T lx = q.x - so.x, ly = q.y - so.y, lz = q.z - so.z;
                         const T tca = lx * L.x + ly * L.y + lz * L.z;
@@ -938,12 +1018,33 @@ __device__ V<double> trace_ext_f64w(RayStack64& stack, const unsigned char* bloc
                         const T d2 = (lx * lx + ly * ly + lz * lz) - tca * tca;
                         open_m &= ~ballot(!(tca < 0) & !(d2 > q.w));                      // any hit blocks; distance ignored (F7)
                     }
+                    if constexpr (GEN) {
+                        for (int j = 0; j < np && open_m != 0ull; j++) {
+                            if (n + j == i) continue;
+                            const ConstD pl = pl64s + 6 * j;
+                            const T ppx = pl[0], ppy = pl[1], ppz = pl[2], pnx = pl[3], pny = pl[4], pnz = pl[5];
+                            const T denom = L.x * pnx + L.y * pny + L.z * pnz;
+                            const T t = ((ppx - so.x) * pnx + (ppy - so.y) * pny + (ppz - so.z) * pnz) / denom;
+                            open_m &= ~ballot(!(denom == 0) & !(t < 0) & (t * t < len2));
+                        }
+                    }
                 }
                 const T tr = lane_of(asked_m & ~open_m) ? T(0) : T(1);
                 ratio = (ratio != ratio) ? ratio : (ratio > 0 ? ratio : T(0));           // Math.max(0, .)
                 dif.x += (col.x * tr) * (ei.x * ratio);
                 dif.y += (col.y * tr) * (ei.y * ratio);
                 dif.z += (col.z * tr) * (ei.z * ratio);
+                if constexpr (GEN) {
+                    if (ks > 0) {
+                        sp = (sp != sp) ? sp : (sp > 0 ? sp : T(0));
+                        T ph = 1, b = sp;
+                        for (unsigned q = pexp; q > 0; q >>= 1) { if (q & 1u) ph = ph * b; b = b * b; }
+                        const T kp = ks * ph;
+                        dif.x += tr * (ei.x * kp);
+                        dif.y += tr * (ei.y * kp);
+                        dif.z += tr * (ei.z * kp);
+                    }
+                }
             }
             acc.x += r.w.x * dif.x; acc.y += r.w.y * dif.y; acc.z += r.w.z * dif.z;
         }
@@ -956,7 +1057,7 @@ __device__ V<double> trace_ext_f64w(RayStack64& stack, const unsigned char* bloc
 #endif
 // ONE: one sample per pixel, a kernel of its own (the sample loop keeps the camera's 30 SGPRs alive through the whole ray tree:
 // with it the kernel spills scalar registers)
-template <bool ONE>
+template <bool ONE, bool GEN>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTR_EXT64_WAVES, PTR_EXT64_WAVES))) render_ext_f64_kernel(RenderArgs a)
 {
     const int lane = threadIdx.x;
@@ -969,7 +1070,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTR_EXT
     st.dbase = ext_lds_i + lane;
     // the camera ray's candidates: the tile culling of render_ext_f32_body (float32 records, float32 margins: certain misses)
     unsigned long long cand = ~0ull;
+#ifdef PTR_EXT64_NO_TILECULL
+    if (false) {
+#else
     if (a.ext_cull_on && a.n <= 64) {
+#endif
         const CullRec* gcull = reinterpret_cast<const CullRec*>(block + a.off_cull);
         const int li = lane < a.n ? lane : a.n;
         const float4 g0 = *reinterpret_cast<const float4*>(&gcull[li].lx);
@@ -994,7 +1099,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTR_EXT
     const int spp = ONE ? 1 : a.spp;
     for (int s = 0; s < spp; s++) {
         const V<double> d = ext_camera_dir<double>(a, x, y, s);
-        const V<double> c = trace_ext_f64w(st, block, a, origin, d, a.max_depth, cand);
+        const V<double> c = trace_ext_f64w<GEN>(st, block, a, origin, d, a.max_depth, cand);
         sum.x += c.x; sum.y += c.y; sum.z += c.z;
     }
     ext_store<double>(a, frame, x, row, sum);
@@ -1006,8 +1111,11 @@ hipError_t launch_render_ext(const RenderArgs& a, int n_frames, bool f64, bool s
     if (stats) hipLaunchKernelGGL((render_ext_kernel<double, true>), grid, dim3(PTR_BLOCK), 0, s, a);
     // (one wave per workgroup, as below: 4-5 % faster than four; more waves per SIMD than the 4 its 120 VGPRs allow cost
     // spills: 5 waves +15 %, 6 waves +45 %)
-    else if (f64 && spheres_only && !lanewise)
-        hipLaunchKernelGGL(a.spp == 1 ? render_ext_f64_kernel<true> : render_ext_f64_kernel<false>, dim3((a.width + 7) / 8, grid.y, n_frames), dim3(64), 0, s, a);
+    else if (f64 && !lanewise) {
+        const auto kernel = spheres_only ? (a.spp == 1 ? render_ext_f64_kernel<true, false> : render_ext_f64_kernel<false, false>)
+                                         : (a.spp == 1 ? render_ext_f64_kernel<true, true> : render_ext_f64_kernel<false, true>);
+        hipLaunchKernelGGL(kernel, dim3((a.width + 7) / 8, grid.y, n_frames), dim3(64), 0, s, a);
+    }
     else if (f64) hipLaunchKernelGGL((render_ext_kernel<double, false>), dim3((a.width + 7) / 8, grid.y, n_frames), dim3(64), 0, s, a);
     else {
         // one wave per workgroup: the waves' run times differ by an order of magnitude (a tile on a transparent sphere

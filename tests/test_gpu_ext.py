@@ -289,6 +289,7 @@ def test_float32_form_with_turned_cameras_bands_and_strips(rdr, scenes):
                     assert np.array_equal(got, whole[part.global_rows(h)]), (cam, strip, part_no)
     finally:
         rdr.set_camera(None)
+        rdr.set_extension(None, None)
 
 
 def test_wave_level_float64_kernel_equals_the_lane_by_lane_one(rdr, scenes):
@@ -332,6 +333,22 @@ def test_wave_level_float64_kernel_equals_the_lane_by_lane_one(rdr, scenes):
             a = rdr.render(240, 135, flags=X, max_depth=5)
             b = rdr.render(240, 135, flags=X | LW, max_depth=5)
             assert np.array_equal(a, b), k
+        # planes and Phong terms (the kernel's GEN form): plane lights, a mirror wall, even / odd / unit exponents; cameras as above
+        from ptr_amd import synthetic as syn
+        soa, planes, phong = syn.planes_scene()
+        for ext in ((planes, phong), (planes, None), (None, phong[:, :soa.shape[1]])):
+            rdr.set_scene(soa); rdr.set_background(syn.BACKGROUND); rdr.set_extension(*ext)
+            for cam in cams:
+                if cam is None:
+                    rdr.set_camera(None)
+                else:
+                    rdr.set_camera(**cam)
+                for (w, h, depth, spp) in ((320, 180, 5, 1), (121, 67, 3, 2)):
+                    a, af = rdr.render(w, h, flags=X, max_depth=depth, spp=spp, seed=4, want_f32=True)
+                    b, bf = rdr.render(w, h, flags=X | LW, max_depth=depth, spp=spp, seed=4, want_f32=True)
+                    assert np.array_equal(a, b) and np.array_equal(af.view(np.uint32), bf.view(np.uint32)), (ext[0] is None, ext[1] is None, cam, w, h)
+        rdr.set_extension(None, None)
+        rdr.set_camera(None)
         # cyclic strips (8 rows: whole tiles, culled; 5 rows: not)
         _load(rdr, scenes["example1"])
         w, h = 200, 120
@@ -347,3 +364,4 @@ def test_wave_level_float64_kernel_equals_the_lane_by_lane_one(rdr, scenes):
                 assert np.array_equal(buf.cpu().numpy().view(np.uint32), whole[part.global_rows(h)]), (strip, part_no)
     finally:
         rdr.set_camera(None)
+        rdr.set_extension(None, None)
