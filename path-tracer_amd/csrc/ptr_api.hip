@@ -185,6 +185,15 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
     }
     // shadow pre-filter table (see PairQ)
     PairQ* pairs = reinterpret_cast<PairQ*>(dst + L.off_pairs);
+    // A culled pair is a miss in EXACT arithmetic: the shadow ray's line stays farther than r + 1e-6 (r + D) from the occluder's
+    // centre (`reach` below minus the bias), i.e. d2 - r^2 > 2e-6 r (r + D).  What every kernel has to agree with, though, is the
+    // reference's FLOAT64 test, which computes d2 = |l|^2 - tca^2 with an error of up to 14 eps |l|^2 (eps = 2^-53): where that
+    // exceeds the margin its outcome is rounding noise, and the noise is the reference's result.  A pair is therefore cullable
+    // only if 8 x 14 eps |l|^2 stays below its margin for every shadow origin ON A SPHERE of the scene
+    // (|l| <= |origin - camera| + |centre - camera|, |origin - camera| <= the farthest sphere's far side).
+    double reach_max = 0.0;
+    for (int j = 0; j < n; j++) reach_max = std::fmax(reach_max, (double)p32[j].lnorm * 1.000001 + std::fabs(pl(3, j)) + 2.0e-4);
+    const double noise = 8.0 * 14.0 * 1.1102230246251565e-16;
     for (int k = 0; k < nl && k < PTR_MAX_PAIR_LIGHTS; k++) {
         const int i = lights[k];
         for (int j = 0; j < n; j++) {
@@ -192,7 +201,9 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
             const double ax = pl(0, j) - pl(0, i), ay = pl(1, j) - pl(1, i), az = pl(2, j) - pl(2, i);
             const double D = std::sqrt(ax * ax + ay * ay + az * az);
             const double reach = std::fabs(pl(3, j)) + 1.0e-4 + 1.0e-6 * (std::fabs(pl(3, j)) + D);   // r + bias + slop
-            if (D > 0 && reach < D && std::isfinite(D)) {
+            const double l_max = reach_max + (double)p32[j].lnorm * 1.000001;
+            const bool conditioned = noise * l_max * l_max < 2.0e-6 * std::fabs(pl(3, j)) * (std::fabs(pl(3, j)) + D);
+            if (D > 0 && reach < D && std::isfinite(D) && conditioned) {
                 const double x = reach / D;
                 const double thr = std::sqrt(1.0 - x * x);
                 q.ax = (float)(ax / D); q.ay = (float)(ay / D); q.az = (float)(az / D);
@@ -207,13 +218,9 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
         for (int j = 0; j < pair_stride(n); j++) pairs[row * (size_t)pair_stride(n) + (size_t)j] = PairQ{0, 0, 0, -1.0f};
     }
     {
-        // The float64 bounce loop must reproduce the specification's float64 arithmetic bit for bit, its rounding included.
-        // A culled (light, occluder) pair is a miss in exact arithmetic: the shadow ray's line stays farther than
-        // r + 1e-6 (r + D) from the occluder's centre (`reach` above minus the bias), i.e. d2 - r^2 > 2e-6 r (r + D).  The
-        // float64 test computes d2 = |l|^2 - tca^2 with an error of up to 14 eps |l|^2 (eps = 2^-53): for a far origin
-        // (a hit point on a plane, anywhere) that exceeds the margin, the test's outcome is rounding noise, and the cull would
-        // differ from it.  So the cull is allowed only while 8 x 14 eps |l|^2 < 2e-6 r (r + D) for every pair, with
-        // |l| <= |origin - camera| + the largest |centre - camera|: one number per frame.
+        // The float64 bounce loop with planes: hit points on a plane lie anywhere, so the conditioning argument above needs a
+        // bound per ray: the cull is allowed only while the shadow origin is within sqrt(pair_smax2) of the camera (the
+        // smallest margin of any cullable pair decides).  Without planes the table is safe as built (pair_always).
         double worst = INFINITY, far = 0.0;
         for (int j = 0; j < n; j++) far = std::fmax(far, (double)p32[j].lnorm);
         for (int k = 0; k < nl && k < PTR_MAX_PAIR_LIGHTS; k++)
@@ -224,13 +231,10 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
                 const double r = std::fabs(pl(3, j));
                 worst = std::fmin(worst, r * (r + std::sqrt(ax * ax + ay * ay + az * az)));
             }
-        const double ll_safe = 2.0e-6 * worst / (8.0 * 14.0 * 1.1102230246251565e-16);
+        const double ll_safe = 2.0e-6 * worst / noise;
         const double smax = std::sqrt(ll_safe) - far * 1.000001;
         h->pair_smax2 = (std::isfinite(smax) && smax > 0) ? (float)(smax * smax * 0.999) : (worst == INFINITY ? 3.0e38f : -1.0f);
-        // hit points on spheres: |P + bias N - camera| <= |centre - camera| + r + bias
-        double reach_max = 0.0;
-        for (int j = 0; j < n; j++) reach_max = std::fmax(reach_max, (double)p32[j].lnorm * 1.000001 + std::fabs(pl(3, j)) + 2.0e-4);
-        h->pair_always = (double)h->pair_smax2 >= reach_max * reach_max * 1.001 ? 1u : 0u;
+        h->pair_always = 1u;              // (every pair left in the table is well conditioned for hit points on spheres)
     }
     {
         float* x4 = reinterpret_cast<float*>(dst + L.off_x4);
