@@ -655,7 +655,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_ext_kernel(RenderArgs a)
 #else
 #define PTR_EXT_OCC
 #endif
-template <bool GEN>
+template <bool GEN, bool ONE>
 __device__ __forceinline__ void render_ext_f32_body(const RenderArgs& a)
 {
     const int lane = threadIdx.x;
@@ -689,7 +689,8 @@ __device__ __forceinline__ void render_ext_f32_body(const RenderArgs& a)
     const int y = global_y(a, row);
     if (x >= a.width || row >= a.scan_height) return;            // (after the culling step: every lane speaks for a sphere there)
     V<float> sum{0, 0, 0};
-    for (int s = 0; s < a.spp; s++) {
+    const int spp = ONE ? 1 : a.spp;                 // (one sample per pixel: a kernel of its own, as in the float64 form)
+    for (int s = 0; s < spp; s++) {
         const V<float> d = ext_camera_dir<float>(a, x, y, s);
         const V<float> c = trace_ext_f32<GEN>(st, block, a, V<float>{0, 0, 0}, d, a.max_depth, cand);
         sum.x += c.x; sum.y += c.y; sum.z += c.z;
@@ -697,7 +698,8 @@ __device__ __forceinline__ void render_ext_f32_body(const RenderArgs& a)
     ext_store<float>(a, frame, x, row, sum);
 }
 
-__global__ void __launch_bounds__(64) PTR_EXT_OCC render_ext_f32_kernel(RenderArgs a) { render_ext_f32_body<false>(a); }
+__global__ void __launch_bounds__(64) PTR_EXT_OCC render_ext_f32_kernel(RenderArgs a) { render_ext_f32_body<false, false>(a); }
+__global__ void __launch_bounds__(64) PTR_EXT_OCC render_ext_f32_one_kernel(RenderArgs a) { render_ext_f32_body<false, true>(a); }
 #ifndef PTR_EXT_GEN_WAVES
 #define PTR_EXT_GEN_WAVES 7
 #endif
@@ -706,7 +708,7 @@ __global__ void __launch_bounds__(64) PTR_EXT_OCC render_ext_f32_kernel(RenderAr
 #else
 #define PTR_EXT_GEN_OCC
 #endif
-__global__ void __launch_bounds__(64) PTR_EXT_GEN_OCC render_ext_f32_gen_kernel(RenderArgs a) { render_ext_f32_body<true>(a); }
+__global__ void __launch_bounds__(64) PTR_EXT_GEN_OCC render_ext_f32_gen_kernel(RenderArgs a) { render_ext_f32_body<true, false>(a); }
 
 // ---- the float64 specification in the wave-level form (scenes of spheres) ---------------------------------------------
 // Bit for bit what trace_ext<double> computes - every lane performs the same float64 operations in the same order - but
@@ -1121,7 +1123,7 @@ hipError_t launch_render_ext(const RenderArgs& a, int n_frames, bool f64, bool s
         // one wave per workgroup: the waves' run times differ by an order of magnitude (a tile on a transparent sphere
         // expands a tree of rays), and a one-wave workgroup starts wherever a slot is free
         const dim3 grid1((a.width + 7) / 8, grid.y, n_frames);
-        if (spheres_only) hipLaunchKernelGGL(render_ext_f32_kernel, grid1, dim3(64), 0, s, a);
+        if (spheres_only) hipLaunchKernelGGL(a.spp == 1 ? render_ext_f32_one_kernel : render_ext_f32_kernel, grid1, dim3(64), 0, s, a);
         else hipLaunchKernelGGL(render_ext_f32_gen_kernel, grid1, dim3(64), 0, s, a);
     }
     return hipGetLastError();
