@@ -58,7 +58,7 @@ void default_camera(ptr_camera& cam)
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct BlockLayout {
-    uint32_t off_g64, off_m64, off_p32, off_m32, off_lights, off_pairs, off_lrec, off_cull, off_x4;
+    uint32_t off_g64, off_m64, off_p32, off_m32, off_lights, off_pairs, off_pairs_x, off_lrec, off_cull, off_x4;
     uint32_t off_pl64, off_plm64, off_pl32, off_plm32, off_ph64, off_ph32;
     size_t   bytes;
 };
@@ -78,6 +78,10 @@ BlockLayout block_layout(int n, int np = 0, bool phong = false)
     // (+ 1 row of never-cull records, used by the lights past the cap)
     o = align_up(o, 64);
     L.off_pairs = (uint32_t)o;
+    o += sizeof(PairQ) * ((size_t)(n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS) + 1) * (size_t)pair_stride(n);
+    o = align_up(o, 64);
+    // ... and the same table for the bounce loop, whose shadow rays start anywhere on the spheres (build_frame_block)
+    L.off_pairs_x = (uint32_t)o;
     o += sizeof(PairQ) * ((size_t)(n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS) + 1) * (size_t)pair_stride(n);
     o = align_up(o, 64);
     L.off_lrec = (uint32_t)o;   o += sizeof(LightRec) * ((size_t)n + 1);
@@ -184,16 +188,22 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
         m32[i] = m;
     }
     // shadow pre-filter table (see PairQ)
-    PairQ* pairs = reinterpret_cast<PairQ*>(dst + L.off_pairs);
     // A culled pair is a miss in EXACT arithmetic: the shadow ray's line stays farther than r + 1e-6 (r + D) from the occluder's
     // centre (`reach` below minus the bias), i.e. d2 - r^2 > 2e-6 r (r + D).  What every kernel has to agree with, though, is the
     // reference's FLOAT64 test, which computes d2 = |l|^2 - tca^2 with an error of up to 14 eps |l|^2 (eps = 2^-53): where that
     // exceeds the margin its outcome is rounding noise, and the noise is the reference's result.  A pair is therefore cullable
-    // only if 8 x 14 eps |l|^2 stays below its margin for every shadow origin ON A SPHERE of the scene
-    // (|l| <= |origin - camera| + |centre - camera|, |origin - camera| <= the farthest sphere's far side).
-    double reach_max = 0.0;
-    for (int j = 0; j < n; j++) reach_max = std::fmax(reach_max, (double)p32[j].lnorm * 1.000001 + std::fabs(pl(3, j)) + 2.0e-4);
+    // only if 8 x 14 eps |l|^2 stays below its margin for every shadow origin the kernels that use the table can produce
+    // (|l| <= |origin - camera| + |centre - camera|).  Two tables: camera rays (reference semantics) end within the tangent
+    // length sqrt(cc) of a sphere seen from outside, within |l| + r of one seen from inside; the bounce loop's rays end
+    // anywhere on the spheres, up to a sphere's far side.
+    double reach_cam = 0.0, reach_max = 0.0;
+    for (int j = 0; j < n; j++) {
+        const double ln = (double)p32[j].lnorm * 1.000001, r = std::fabs(pl(3, j)), cc = ln * ln - r * r;
+        reach_cam = std::fmax(reach_cam, (cc > 0 ? std::sqrt(cc) : ln + r) + 2.0e-4);
+        reach_max = std::fmax(reach_max, ln + r + 2.0e-4);
+    }
     const double noise = 8.0 * 14.0 * 1.1102230246251565e-16;
+    auto fill_pairs = [&](PairQ* pairs, double reach_bound) {
     for (int k = 0; k < nl && k < PTR_MAX_PAIR_LIGHTS; k++) {
         const int i = lights[k];
         for (int j = 0; j < n; j++) {
@@ -201,7 +211,7 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
             const double ax = pl(0, j) - pl(0, i), ay = pl(1, j) - pl(1, i), az = pl(2, j) - pl(2, i);
             const double D = std::sqrt(ax * ax + ay * ay + az * az);
             const double reach = std::fabs(pl(3, j)) + 1.0e-4 + 1.0e-6 * (std::fabs(pl(3, j)) + D);   // r + bias + slop
-            const double l_max = reach_max + (double)p32[j].lnorm * 1.000001;
+            const double l_max = reach_bound + (double)p32[j].lnorm * 1.000001;
             const bool conditioned = noise * l_max * l_max < 2.0e-6 * std::fabs(pl(3, j)) * (std::fabs(pl(3, j)) + D);
             if (D > 0 && reach < D && std::isfinite(D) && conditioned) {
                 const double x = reach / D;
@@ -217,6 +227,10 @@ bool build_frame_block(unsigned char* dst, const BlockLayout& L, const double* s
         const size_t row = (size_t)(n < PTR_MAX_PAIR_LIGHTS ? n : PTR_MAX_PAIR_LIGHTS);
         for (int j = 0; j < pair_stride(n); j++) pairs[row * (size_t)pair_stride(n) + (size_t)j] = PairQ{0, 0, 0, -1.0f};
     }
+    };
+    fill_pairs(reinterpret_cast<PairQ*>(dst + L.off_pairs), reach_cam);
+    PairQ* pairs = reinterpret_cast<PairQ*>(dst + L.off_pairs_x);
+    fill_pairs(pairs, reach_max);
     {
         // The float64 bounce loop with planes: hit points on a plane lie anywhere, so the conditioning argument above needs a
         // bound per ray: the cull is allowed only while the shadow origin is within sqrt(pair_smax2) of the camera (the
@@ -511,7 +525,7 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
     a.frame_stride = c->frame_stride;
     {
         const BlockLayout L = block_layout(c->n_spheres);
-        a.off_p32 = L.off_p32; a.off_m32 = L.off_m32; a.off_lights = L.off_lights; a.off_pairs = L.off_pairs; a.off_lrec = L.off_lrec; a.off_cull = L.off_cull; a.off_x4 = L.off_x4;
+        a.off_p32 = L.off_p32; a.off_m32 = L.off_m32; a.off_lights = L.off_lights; a.off_pairs = plan.extension ? L.off_pairs_x : L.off_pairs; a.off_lrec = L.off_lrec; a.off_cull = L.off_cull; a.off_x4 = L.off_x4;
         a.n = c->n_spheres;
     }
     a.first_frame = 0;
