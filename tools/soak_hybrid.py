@@ -2,7 +2,7 @@
 The float64 kernel is pinned to the CPU oracle and the reference's golden frames by tests/; this script looks for pixels
 where an error bound of the float32 kernel is too tight (any difference is a bug).  Usage: python tools/soak_hybrid.py [scenes] [seed] [max_spheres = 12]
 (more than 12 spheres: the two-level kernel of ptr_kernels_many.hip)
-PTR_SOAK_MODE=tolerant: PTR_MODE_TOLERANT instead, and "differ" means "differ by more than one unit in some channel"."""
+PTR_SOAK_SCALE=1: every fourth scene has tiny / huge coordinates or radii.  PTR_SOAK_MODE=tolerant: PTR_MODE_TOLERANT instead, and "differ" means "differ by more than one unit in some channel"."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "path-tracer_amd", "py")]
@@ -30,6 +30,11 @@ for t in range(n_scenes):
     soa[9:12, lights] = rng.uniform(0.05, 2.0, (3, int(lights.sum())))
     if kind == 0 and n > 1:
         soa[0:4, 0] = [0, -10000 - rng.uniform(2, 6), -20, 10000]; soa[9:12, 0] = 0
+    if os.environ.get("PTR_SOAK_SCALE") and t % 4 == 3:            # the whole scene scaled (tiny / huge coordinates), or single spheres
+        if t % 8 == 3:
+            soa[0:4] *= float(rng.choice([1e-4, 1e-2, 50.0, 1e3, 1e5]))
+        else:
+            soa[3] *= rng.choice([1e-3, 0.05, 1.0, 8.0], n)
     bg = rng.uniform(0, 2.0, 3)
     if t % 3 == 2:
         org = rng.uniform(-8, 8, 3); fwd = rng.normal(size=3); fwd /= np.linalg.norm(fwd)
