@@ -400,6 +400,7 @@ __device__ V<float> trace_ext_f32(Stack& stack, const unsigned char* block, cons
         SphereM32 m;
         float4 ce;
         float refl, transp;
+        [[maybe_unused]] float inv_r = 1.0f;
         if (on_plane) {
             const PlaneP32 pl = gpl32[e - n];
             m = gplm32[e - n];
@@ -408,16 +409,28 @@ __device__ V<float> trace_ext_f32(Stack& stack, const unsigned char* block, cons
         } else {
             m = gm32[e];
             ce = *reinterpret_cast<const float4*>(&gp32[e].lx);
-            refl = gp32[e].refl; transp = gp32[e].transp;
+            const float4 g3 = *reinterpret_cast<const float4*>(&gp32[e].inv_r);      // inv_r hed refl transp
+            refl = g3.z; transp = g3.w; inv_r = g3.x;
         }
         ax = fmaf(r.w.x, m.er, ax); ay = fmaf(r.w.y, m.eg, ay); az = fmaf(r.w.z, m.eb, az);
-        const V<float> P{fmaf(r.d.x, tnear, r.o.x), fmaf(r.d.y, tnear, r.o.y), fmaf(r.d.z, tnear, r.o.z)};
+        V<float> P{fmaf(r.d.x, tnear, r.o.x), fmaf(r.d.y, tnear, r.o.y), fmaf(r.d.z, tnear, r.o.z)};
         V<float> N{P.x - ce.x, P.y - ce.y, P.z - ce.z};
         {
             const float inv = rsq(fmaf(N.z, N.z, fmaf(N.y, N.y, N.x * N.x)));
             N.x *= inv; N.y *= inv; N.z *= inv;
         }
         if (on_plane) N = V<float>{ce.x, ce.y, ce.z};
+#ifndef PTR_EXT_NO_SNAP
+        else {
+            // The hit point, put back ON the sphere: o + d t is off by eps (|o| + t) in every direction, and radially that can
+            // exceed the 1e-4 by which the next ray's origin is moved off the surface (a small sphere far away: the refracted
+            // ray then starts on the wrong side and the whole sphere comes out wrong).  C + r N is on the surface to eps (|C| + r).
+            // (only where that is the smaller error: a sphere smaller than the ray is long)
+            const float rr = rcp(inv_r);
+            const bool snap = rr < tnear;
+            P = V<float>{snap ? fmaf(N.x, rr, ce.x) : P.x, snap ? fmaf(N.y, rr, ce.y) : P.y, snap ? fmaf(N.z, rr, ce.z) : P.z};
+        }
+#endif
         float dn = fmaf(r.d.z, N.z, fmaf(r.d.y, N.y, r.d.x * N.x));
         const bool inside = dn > 0.0f;
         if (inside) { N.x = -N.x; N.y = -N.y; N.z = -N.z; dn = -dn; }
