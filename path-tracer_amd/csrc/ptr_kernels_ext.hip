@@ -815,11 +815,17 @@ __device__ V<double> trace_ext_f64w(RayStack64& stack, const unsigned char* bloc
     bool have = true;
     bool first = true;
     V<T> acc{0, 0, 0};
+#ifdef PTR_EXT64_UTIL
+    unsigned u_lane = 0u, u_wave = 0u, u_blane = 0u, u_bwave = 0u;      // ray steps of this lane / of its wave, those that bounce
+#endif
     while (have || top > 0) {
         if (!have) r = stack.pop(--top);
         have = false;
         T tnear = T(PTR_INFINITY);
         int e = -1;
+#ifdef PTR_EXT64_UTIL
+        u_lane++;
+#endif
         if (n > 0) {
             // Sphere.intersect (Sphere.js:15-33) + RayTracer.js:32-36 for one sphere and all lanes
             auto test = [&](const d4v q, int i) {
@@ -892,6 +898,9 @@ __device__ V<double> trace_ext_f64w(RayStack64& stack, const unsigned char* bloc
         if (dn > 0) { N.x = -N.x; N.y = -N.y; N.z = -N.z; inside = true; dn = -dn; }
         const T transp = m.transp, refl = m.refl;
         if ((transp > 0 || refl > 0) && r.depth < max_depth) {
+#ifdef PTR_EXT64_UTIL
+            u_blane++;
+#endif
             const T facing = -dn;
             const T f = 1 - facing;
             const T fresnel = T(1) * T(0.1) + (f * f * f) * (T(1) - T(0.1));
@@ -1031,6 +1040,16 @@ __device__ V<double> trace_ext_f64w(RayStack64& stack, const unsigned char* bloc
             acc.x += r.w.x * dif.x; acc.y += r.w.y * dif.y; acc.z += r.w.z * dif.z;
         }
     }
+#ifdef PTR_EXT64_UTIL
+    // measurement build (tools/ext64_util.py): the pixel's value is its counts, not its colour.  A lane takes part in every pass
+    // of the loop until its own tree is done, so the wave's passes are the largest count of its lanes.
+    u_wave = u_lane; u_bwave = u_blane;
+    for (int sh = 1; sh < 64; sh <<= 1) {
+        const unsigned o1 = (unsigned)__shfl_xor((int)u_wave, sh), o2 = (unsigned)__shfl_xor((int)u_bwave, sh);
+        u_wave = o1 > u_wave ? o1 : u_wave; u_bwave = o2 > u_bwave ? o2 : u_bwave;
+    }
+    acc.x = (double)(u_lane | (u_wave << 8) | (u_blane << 16) | (u_bwave << 24));
+#endif
     return acc;
 }
 
@@ -1084,7 +1103,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTR_EXT
         const V<double> c = trace_ext_f64w<GEN>(st, block, a, origin, d, a.max_depth, cand);
         sum.x += c.x; sum.y += c.y; sum.z += c.z;
     }
+#ifdef PTR_EXT64_UTIL
+    a.out8[frame * a.out_frame_stride + (uint64_t)a.width * row + x] = (unsigned)sum.x;
+#else
     ext_store<double>(a, frame, x, row, sum);
+#endif
 }
 
 hipError_t launch_render_ext(const RenderArgs& a, int n_frames, bool f64, bool stats, bool spheres_only, bool lanewise, hipStream_t s)
