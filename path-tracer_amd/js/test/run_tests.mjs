@@ -7,6 +7,7 @@ import path from 'path';
 import { fileURLToPath } from 'url';
 import assert from 'assert';
 import { Worker } from 'worker_threads';
+import { spawnSync } from 'child_process';
 import { Plane, Vector3, Material, Sphere, Scene, Color, Camera, RayTracer, RenderPlanner, RenderCache, RenderCacheDriver, RcCamera, createRenderWorker } from '../index.js';
 
 const here = path.dirname(fileURLToPath(import.meta.url));
@@ -587,6 +588,31 @@ async function gpuTests() {
         rt.scene = buildExample1();
         assert.ok(sameBytes(new Uint8Array(rt.render(64, 48)), u8(index.frames['example1@64x48'].file)));
         rt.dispose();
+    });
+    test('examples/: the four Node examples run as programs; example1-3 reproduce the reference\'s frames', () => {
+        const run = (file, ...a) => {
+            const r = spawnSync(process.execPath, [path.join(here, '..', 'examples', file), ...a], { encoding: 'utf8', timeout: 120000 });
+            assert.strictEqual(r.status, 0, `${file} ${a.join(' ')}: ${r.stderr}${r.stdout}`);
+            return r.stdout;
+        };
+        const sha = (out) => /sha256.*?\b([0-9a-f]{64})\b/.exec(out)[1];
+        // example1: exits non-zero by itself when the frame is not the unmodified reference's
+        assert.strictEqual(sha(run('example1.js')), index.hashes['example1@640x480'].sha256);
+        assert.strictEqual(sha(run('example1.js', '--mode', 'exact', '--width', '1920', '--height', '1080')), index.hashes['example1@1920x1080'].sha256);
+        assert.ok(/Render completed/.test(run('example1.js', '--mode', 'tolerant', '--width', '320', '--height', '200')));
+        // example2: the animated scene at clock value 1234 is a golden frame of the reference
+        assert.strictEqual(sha(run('example2.js', '--frames', '1', '--t0', '1234', '--width', '64', '--height', '48')), index.frames['anim_t1234@64x48'].sha256);
+        assert.ok(/FPS = /.test(run('example2.js', '--frames', '20', '--width', '320', '--height', '240')));
+        // example3: 8 bands put together, in-process renderers and real Workers
+        const bands = index.bands['example1@320x240/8'];
+        assert.strictEqual(sha(run('example3.js', '--still', '--frames', '3', '--width', '320', '--height', '240')), bands.sha256);
+        assert.strictEqual(sha(run('example3.js', '--still', '--threads', '--jobs', '8', '--frames', '2', '--width', '320', '--height', '240')), bands.sha256);
+        assert.ok(/Total Frames: 10/.test(run('example3.js', '--frames', '10', '--width', '320', '--height', '240')));
+        // example4: the render-cache loop, resident and host form leave the same frame (seeded Math.random)
+        const a = run('example4.js', '--frames', '6', '--width', '96', '--height', '64', '--ratio', '8');
+        const b = run('example4.js', '--frames', '6', '--width', '96', '--height', '64', '--ratio', '8', '--host');
+        assert.strictEqual(sha(a), sha(b));
+        assert.ok(/rays requested/.test(a));
     });
     test('stats(): the reference ray mix at 640x480 (SURVEY 6)', () => {
         const rt = new RayTracer(new Vector3(2, 2, 2), buildExample1());

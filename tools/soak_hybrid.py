@@ -57,6 +57,8 @@ for t in range(n_scenes):
     if bad:
         idx = np.flatnonzero(got != want)[:3]
         print(f"scene {t} (kind {kind}, n={n}, {w}x{h}): {bad} pixels differ, first {[(int(i % w), int(i // w), hex(int(got[i])), hex(int(want[i]))) for i in idx]}", flush=True)
+    if (t + 1) % 20000 == 0 and t + 1 < n_scenes:            # a long run must show that it is alive
+        print(f"... {t + 1} scenes, {px_total} pixels, {bad_total} differ so far", flush=True)
 print(f"{n_scenes} scenes, {px_total} pixels, {redo_total} re-done in float64 ({100.0 * redo_total / px_total:.2f} %), {bad_total} differ"
       + (f" by more than one unit; {one_unit} by one unit ({100.0 * one_unit / px_total:.4f} %)" if TOL else ""))
 sys.exit(1 if bad_total else 0)
