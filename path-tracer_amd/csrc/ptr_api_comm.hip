@@ -355,8 +355,7 @@ int ptr_render_multi(ptr_ctx* const* ctxs, int n, const ptr_params* p, uint32_t*
     PTR_TRY(ptr_gather_strips_all(ctxs, n, p->width, p->height, STRIP, 1, locals, stride, root->multi_full.ptr));
     std::lock_guard<std::mutex> lk(root->mu);
     HIP_TRY(root, hipSetDevice(root->device));
-    HIP_TRY(root, hipMemcpyAsync(out_rgba8, root->multi_full.ptr, px * sizeof(uint32_t), hipMemcpyDeviceToHost, root->stream));
-    HIP_TRY(root, hipStreamSynchronize(root->stream));
+    PTR_TRY(copy_to_host(root, out_rgba8, root->multi_full.ptr, px * sizeof(uint32_t), root->stream));
     for (int i = 1; i < n; i++) {                              // the peers' sends are done once the root has everything; leave no work behind
         HIP_TRY(ctxs[i], hipSetDevice(ctxs[i]->device));
         HIP_TRY(ctxs[i], hipStreamSynchronize(ctxs[i]->stream));

@@ -521,8 +521,7 @@ int ptr_rc_get_frames(ptr_ctx* c, uint32_t* color_frame, uint32_t* reprojection_
     for (int k = 0; k < 4; k++) a.frames[k] = host[k] ? static_cast<uint32_t*>(r.frames.ptr) + (size_t)k * px : nullptr;
     HIP_TRY(c, launch_rc_frames(a, s));
     for (int k = 0; k < 4; k++)
-        if (host[k]) HIP_TRY(c, hipMemcpyAsync(host[k], a.frames[k], px * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+        if (host[k]) PTR_TRY(copy_to_host(c, host[k], a.frames[k], px * 4, s));
     return PTR_OK;
 }
 

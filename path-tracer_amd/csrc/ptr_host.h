@@ -111,6 +111,11 @@ struct ptr_ctx {
     int comm_rank = 0, comm_n = 0;          // comm_n 0: no communicator
     DeviceBuffer gather_stage;              // root: the peers' local buffers as they arrive
     DeviceBuffer multi_local, multi_full;   // ptr_render_multi: this GPU's part / the whole frame on the root
+    // frames that go to PAGEABLE host memory (ptr_render, ptr_render_multi, ptr_rc_get_frames): two page-locked halves that the
+    // copy engine fills in turn while the CPU empties the other into the caller's buffer (copy_to_host)
+    unsigned char* host_stage = nullptr;
+    size_t host_stage_half = 0;
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
     unsigned char* stats_words = nullptr;   // where the last call's kernels put their stats words
     unsigned char* scratch_dev = nullptr;   // this GPU's address of the static array `scratch`
 };
@@ -130,6 +135,10 @@ int fail(ptr_ctx* c, int code, const char* fmt, ...);
     do { int rc_ = (expr); if (rc_ != PTR_OK) return rc_; } while (0)
 
 int grow(ptr_ctx* c, DeviceBuffer& b, size_t bytes);
+// device -> host on stream s, complete on return.  A page-locked destination takes one DMA; a pageable one is filled through
+// the context's two page-locked halves (the driver's own path for pageable memory runs at a third of the link's rate).
+int copy_to_host(ptr_ctx* c, void* dst, const void* d_src, size_t bytes, hipStream_t s);
+constexpr size_t HOST_STAGE_MIN = (size_t)256 << 10, HOST_STAGE_MAX_HALF = (size_t)1 << 20;
 void rc_cache_free(ptr_ctx* c);
 bool stream_is_capturing(hipStream_t s);
 int order_after_last(ptr_ctx* c, hipStream_t s);      // make s wait for the context's most recent call on another stream

@@ -13,6 +13,7 @@
  *   setCamera(h, Float64Array(13) | null)                                    ptr_set_camera
  *   setExtension(h, Float64Array planes | null, nPlanes, Float64Array phong | null, nElements)   ptr_set_extension_f64
  *   render(h, w, height, startY, scanHeight, flags)  -> ArrayBuffer (RGBA8)  ptr_render
+ *   renderInto(h, target, w, height, startY, scanHeight, flags) -> target  ptr_render (into the caller's own memory)
  *   renderAsync(h, w, height, startY, scanHeight, flags) -> Promise<ArrayBuffer>
  *   traceSamples(h, Float64Array origin(3), Float64Array dirs) -> {rgb, rgb8, hit, normal}   ptr_trace_samples_f64
  *   traceBatch(h, Float64Array origins | null, Float64Array dirs)
@@ -294,6 +295,44 @@ static napi_value js_render(napi_env env, napi_callback_info info)
     int rc = ptr_render(ctx, &p, (uint32_t *)data, NULL);
     if (rc != PTR_OK) return throw_ptr(env, ctx, rc);
     return buf;            /* a fresh ArrayBuffer owned by the caller, RT/src/RayTracer.js:148,196 */
+}
+
+/* renderInto(h, target, w, height, startY, scanHeight, flags[, maxDepth, spp, seed]): the same frame into memory the caller
+ * already has (an ArrayBuffer or a typed array of at least w * scanHeight * 4 bytes).  A loop that renders frame after frame
+ * spends more time on a fresh ArrayBuffer per frame (allocation, first-touch page faults, garbage collection) than on the
+ * frame itself; the reference's API hands out a new buffer per call, so render() keeps doing that and this is the addition. */
+static napi_value js_render_into(napi_env env, napi_callback_info info)
+{
+    napi_value argv[10];
+    if (!get_args_opt(env, info, 7, 10, argv)) return NULL;
+    ptr_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    ptr_params p;
+    if (!read_params(env, argv + 2, &p) || !check_frame_size(env, &p)) return NULL;
+    void *data = NULL;
+    size_t bytes = 0;
+    bool is_ab = false, is_ta = false;
+    if (napi_is_arraybuffer(env, argv[1], &is_ab) == napi_ok && is_ab) {
+        NAPI_TRY(env, napi_get_arraybuffer_info(env, argv[1], &data, &bytes));
+    } else if (napi_is_typedarray(env, argv[1], &is_ta) == napi_ok && is_ta) {
+        napi_typedarray_type tt;
+        size_t len = 0;
+        NAPI_TRY(env, napi_get_typedarray_info(env, argv[1], &tt, &len, &data, NULL, NULL));
+        const size_t width = (tt == napi_int8_array || tt == napi_uint8_array || tt == napi_uint8_clamped_array) ? 1
+                           : (tt == napi_int16_array || tt == napi_uint16_array) ? 2
+                           : (tt == napi_int32_array || tt == napi_uint32_array || tt == napi_float32_array) ? 4 : 8;
+        bytes = len * width;
+    } else {
+        napi_throw_type_error(env, NULL, "target must be an ArrayBuffer or a typed array");
+        return NULL;
+    }
+    if (bytes < (size_t)p.width * (size_t)p.scan_height * 4 || ((uintptr_t)data & 3u)) {
+        napi_throw_range_error(env, "PTR_ERR_INVALID", "target must hold width * scanHeight * 4 bytes, 4-byte aligned");
+        return NULL;
+    }
+    int rc = ptr_render(ctx, &p, (uint32_t *)data, NULL);
+    if (rc != PTR_OK) return throw_ptr(env, ctx, rc);
+    return argv[1];
 }
 
 /* ---- renderAsync: the worker-shaped path (RT/src/RenderWorker.js:55-70) ------------------- */
@@ -785,7 +824,7 @@ NAPI_MODULE_INIT()
 {
     const struct { const char *name; napi_callback fn; } fns[] = {
         {"create", js_create}, {"destroy", js_destroy}, {"setScene", js_set_scene},
-        {"setBackground", js_set_background}, {"setCamera", js_set_camera}, {"setExtension", js_set_extension}, {"render", js_render},
+        {"setBackground", js_set_background}, {"setCamera", js_set_camera}, {"setExtension", js_set_extension}, {"render", js_render}, {"renderInto", js_render_into},
         {"renderAsync", js_render_async}, {"traceBatch", js_trace_batch}, {"traceSamples", js_trace_samples}, {"rcReproject", js_rc_reproject}, {"rcShade", js_rc_shade}, {"stats", js_stats},
         {"commInitAll", js_comm_init_all}, {"renderMulti", js_render_multi},
         {"rcCacheCreate", js_rc_cache_create}, {"rcCacheDestroy", js_rc_cache_destroy}, {"rcCacheUpload", js_rc_cache_upload},

@@ -2,18 +2,21 @@
 // (assigned, `sphere.center = new Vector3(...)`: the renderer re-reads the scene objects on every call) and the whole
 // frame is rendered again.  The browser's setInterval / Date.now() become a loop over a clock that advances by --step
 // milliseconds per frame, so a run is reproducible.
-//   node examples/example2.js [--frames 300] [--width 640] [--height 480] [--t0 0] [--step 10] [--mode hybrid] [--out last.ppm]
+//   node examples/example2.js [--frames 300] [--width 640] [--height 480] [--t0 0] [--step 10] [--mode hybrid] [--reuse] [--out last.ppm]
+// --reuse: every frame into ONE buffer (RayTracer.renderInto) instead of a new ArrayBuffer per frame, which is what the
+// reference's API hands out and what costs most of a frame's time here.
 // `--frames 1 --t0 1234 --width 64 --height 48` is the frame tests/golden/frames/anim_t1234_64x48.rgba holds.
 import { RayTracer } from '../index.js';
 import { exampleScene, animate, sha256, writePPM, args } from './common.js';
 
-const opt = args({ frames: 300, width: 640, height: 480, t0: 0, step: 10, mode: 'hybrid', out: '' });
+const opt = args({ frames: 300, width: 640, height: 480, t0: 0, step: 10, mode: 'hybrid', reuse: false, out: '' });
 const { scene, backgroundColor, moving } = exampleScene();
 const rayTracer = new RayTracer(backgroundColor, scene, undefined, { mode: opt.mode });
 
 let isFirstFrame = 0, buffer = null, reTraced = 0;
 function render() {
-    buffer = rayTracer.render(opt.width, opt.height, undefined, undefined, isFirstFrame);
+    if (opt.reuse) buffer = rayTracer.renderInto(buffer || new ArrayBuffer(opt.width * opt.height * 4), opt.width, opt.height);
+    else buffer = rayTracer.render(opt.width, opt.height, undefined, undefined, isFirstFrame);
     isFirstFrame = 1;
     reTraced += rayTracer.stats().retraced;
     return new Uint8ClampedArray(buffer);

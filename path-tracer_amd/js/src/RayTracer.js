@@ -13,7 +13,7 @@ import Plane from './Plane.js';
  *   .requestPixel(rayDir) -> Color {r, g, b}
  *
  * plus renderAsync() (Promise form, for RenderPlanner), renderFrame() (all rows at their true
- * position) and traceBatch().  The scene is re-read from the Scene/Sphere/Material objects on
+ * position), renderInto() (the frame into a buffer of the caller's) and traceBatch().  The scene is re-read from the Scene/Sphere/Material objects on
  * every call (the reference's examples mutate `sphere.center` between frames); nothing is
  * cached on add().  The user's backgroundColor object is never modified (the reference clamps it
  * in place as a side effect of returning it from trace(); do not rely on that).
@@ -125,6 +125,21 @@ export default class RayTracer {
         const d = RayTracer._dims(width, height, startY, scanHeight);
         this._upload(false);
         return this._native.render(this._handle, d[0], d[1], d[2], d[3], this._native.QUIRK_ROW_SHIFT | this._modeFlags);
+    }
+
+    /**
+     * render() into memory the caller already has: `target` is an ArrayBuffer or a typed array of at least
+     * width * scanHeight * 4 bytes; returns it.  Same bytes as render() (row quirk included).  For loops that render frame
+     * after frame: a fresh ArrayBuffer per frame (allocation, first-touch page faults, garbage collection) costs more than
+     * a 1080p frame does.  options: {startY, scanHeight, exact: false -> every row at its true position, maxDepth, spp, seed}
+     */
+    renderInto(target, width, height, options = {}) {
+        const d = RayTracer._dims(width, height, options.startY, options.scanHeight);
+        const plain = options.exact === false || options.maxDepth || (options.spp || 1) > 1;     // the extension modes have no row quirk
+        const e = RayTracer._ext(options);
+        this._upload(!!options.useCamera);
+        return this._native.renderInto(this._handle, target, d[0], d[1], d[2], d[3],
+                                       (plain ? 0 : this._native.QUIRK_ROW_SHIFT) | this._modeFlags, e[0], e[1], e[2]);
     }
 
     /** Promise<ArrayBuffer> form of render() (runs off the main thread). */

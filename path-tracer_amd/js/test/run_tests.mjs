@@ -602,6 +602,7 @@ async function gpuTests() {
         assert.ok(/Render completed/.test(run('example1.js', '--mode', 'tolerant', '--width', '320', '--height', '200')));
         // example2: the animated scene at clock value 1234 is a golden frame of the reference
         assert.strictEqual(sha(run('example2.js', '--frames', '1', '--t0', '1234', '--width', '64', '--height', '48')), index.frames['anim_t1234@64x48'].sha256);
+        assert.strictEqual(sha(run('example2.js', '--reuse', '--frames', '3', '--step', '0', '--t0', '1234', '--width', '64', '--height', '48')), index.frames['anim_t1234@64x48'].sha256);
         assert.ok(/FPS = /.test(run('example2.js', '--frames', '20', '--width', '320', '--height', '240')));
         // example3: 8 bands put together, in-process renderers and real Workers
         const bands = index.bands['example1@320x240/8'];
@@ -613,6 +614,31 @@ async function gpuTests() {
         const b = run('example4.js', '--frames', '6', '--width', '96', '--height', '64', '--ratio', '8', '--host');
         assert.strictEqual(sha(a), sha(b));
         assert.ok(/rays requested/.test(a));
+    });
+    test('renderInto(): the frame in the caller\'s own buffer equals render()\'s; wrong targets are refused', () => {
+        const rt = new RayTracer(new Vector3(2, 2, 2), buildExample1());
+        const want = new Uint8Array(rt.render(160, 120));
+        assert.ok(sameBytes(want, u8(index.frames['example1@160x120'].file)));
+        const ab = new ArrayBuffer(160 * 120 * 4);
+        assert.strictEqual(rt.renderInto(ab, 160, 120), ab);
+        assert.ok(sameBytes(new Uint8Array(ab), want));
+        const big = new Uint32Array(160 * 120 + 7).fill(0xdeadbeef);           // a typed array with room to spare: the rest stays
+        rt.renderInto(big, 160, 120);
+        assert.ok(sameBytes(new Uint8Array(big.buffer, 0, 160 * 120 * 4), want));
+        assert.strictEqual(big[160 * 120], 0xdeadbeef);
+        const view = new Uint8ClampedArray(new ArrayBuffer(160 * 120 * 4 + 16), 8, 160 * 120 * 4);    // an offset view
+        rt.renderInto(view, 160, 120);
+        assert.ok(sameBytes(view, want));
+        const band = new Uint8Array(160 * 30 * 4);
+        rt.renderInto(band, 160, 120, { startY: 30, scanHeight: 30 });
+        assert.ok(sameBytes(band, new Uint8Array(rt.render(160, 120, 30, 30))));
+        const whole = new Uint8Array(160 * 120 * 4);
+        rt.renderInto(whole, 160, 120, { exact: false });
+        assert.ok(sameBytes(whole, new Uint8Array(rt.renderFrame(160, 120))));
+        assert.throws(() => rt.renderInto(new ArrayBuffer(100), 160, 120), RangeError);
+        assert.throws(() => rt.renderInto(new Uint8Array(new ArrayBuffer(160 * 120 * 4 + 8), 1, 160 * 120 * 4), 160, 120), RangeError);
+        assert.throws(() => rt.renderInto({}, 160, 120), TypeError);
+        rt.dispose();
     });
     test('stats(): the reference ray mix at 640x480 (SURVEY 6)', () => {
         const rt = new RayTracer(new Vector3(2, 2, 2), buildExample1());
