@@ -96,7 +96,9 @@ typedef struct ptr_ctx ptr_ctx;
  * With max_depth 0 and spp 1 a call has the reference semantics.  In the extension modes the default (no mode bit) and
  * PTR_MODE_EXACT_F64 render that specification bit for bit in float64; PTR_MODE_F32_ONLY renders it in float32, the
  * throughput form (tolerance: see tests/test_gpu_ext.py - PSNR > 50 dB, but single pixels on discontinuities and their
- * mirror images can be off by more than 1/255, which is why it is not the default); PTR_QUIRK_ROW_SHIFT is rejected.  */
+ * mirror images can be off by more than 1/255, which is why it is not the default; its samples are added up in blocks of 32
+ * consecutive samples, then the blocks' sums in order - with at most 32 samples that is the plain sum - so that a pixel's
+ * blocks can be traced by different waves: same bytes whether they are or not); PTR_QUIRK_ROW_SHIFT is rejected.  */
 #define PTR_MAX_DEPTH_LIMIT 16
 #define PTR_MAX_SPP         65536
 typedef struct ptr_params {

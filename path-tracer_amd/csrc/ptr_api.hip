@@ -651,6 +651,18 @@ int enqueue_render(ptr_ctx* c, const ptr_params* p, int first_frame, int n_frame
         // error bounds yet that would tell which pixels to re-do (errors grow with every bounce off a curved surface), and
         // the contract is <= 1/255 on every pixel.  PTR_MODE_F32_ONLY asks for the float32 throughput form explicitly.
         a.max_depth = p->max_depth; a.spp = p->spp; a.seed = p->seed;
+        a.ext_blocks = (p->spp + PTR_EXT_SPP_BLOCK - 1) / PTR_EXT_SPP_BLOCK;
+        const bool f32_form = !exact && (p->flags & PTR_MODE_F32_ONLY) && !stats;
+        if (f32_form && a.ext_blocks > 1 && !fixed_ws && (uint64_t)n_frames * (uint64_t)a.ext_blocks <= 65535u) {
+            // a wave per block of samples (ptr_kernels_ext.hip): room for the blocks' sums, unless that is out of proportion
+            // (then, and for the caller that cannot allocate, every wave takes all blocks of its pixels: same bytes)
+            const uint64_t bytes = (uint64_t)n_frames * (uint64_t)a.ext_blocks * (uint64_t)p->width * (uint64_t)p->scan_height * 16u;
+            if (bytes <= EXT_PARTIAL_MAX_BYTES) {
+                PTR_TRY(order_after_last(c, s));
+                PTR_TRY(grow(c, c->ext_partial, (size_t)bytes));
+                a.ext_partial = static_cast<float*>(c->ext_partial.ptr);
+            }
+        }
         HIP_TRY(c, launch_render_ext(a, n_frames, exact || !(p->flags & PTR_MODE_F32_ONLY), stats, c->n_planes == 0 && c->n_phong == 0,
                                      (p->flags & PTR_DEBUG_EXT_LANEWISE) != 0, s));
         if (timing) { HIP_TRY(c, hipEventRecord(c->ev[1], s)); c->timed_kernels = 1; }
@@ -787,7 +799,7 @@ void ptr_destroy(ptr_ctx* c)
     if (c->have_last) (void)hipEventSynchronize(c->last_ev);     // kernels enqueued on a caller's stream still read our buffers
     if (c->comm) (void)ptr_comm_destroy(c);
     rc_cache_free(c);
-    for (DeviceBuffer* b : {&c->gather_stage, &c->multi_local, &c->multi_full, &c->scenes, &c->queue, &c->words, &c->out8, &c->out32f, &c->tr_in_o,
+    for (DeviceBuffer* b : {&c->gather_stage, &c->multi_local, &c->multi_full, &c->scenes, &c->queue, &c->words, &c->ext_partial, &c->out8, &c->out32f, &c->tr_in_o,
                             &c->tr_in_d, &c->tr_rgb, &c->tr_el, &c->tr_hit, &c->tr_nrm, &c->rc_depth, &c->rc_keys,
                             &c->rc_temp, &c->rc_hit, &c->rc_age, &c->rc_item, &c->rc_pel, &c->rc_pdep, &c->rc_rgb,
                             &c->rc_prgb, &c->rc_pprio, &c->rc_hist, &c->rc_frames, &c->rc_page, &c->rcm_before, &c->rcm_local_el,

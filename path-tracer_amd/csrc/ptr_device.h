@@ -193,7 +193,17 @@ struct RenderArgs {
     unsigned long long* stats;       // 8 words, see ptr_stats
     int32_t   max_depth, spp;        // extension modes (ptr_kernels_ext.hip)
     uint32_t  seed;
+    // float32 bounce loop with more than PTR_EXT_SPP_BLOCK samples per pixel: a wave takes ONE block of samples of its tile and
+    // leaves the block's sum here, [frame][block][row][x] as float4; ext_combine_kernel adds the blocks up in order.
+    // NULL: every wave takes all samples of its pixels (same sums in the same order, in registers).
+    float*    ext_partial;
+    int32_t   ext_blocks;            // blocks per pixel = ceil(spp / PTR_EXT_SPP_BLOCK)
 };
+
+// The float32 forms of the extension modes add a pixel's samples up block by block: the sum of every PTR_EXT_SPP_BLOCK
+// consecutive samples first, then the blocks' sums in order.  With at most that many samples it is the plain sum.  (The float64
+// form is the specification: one running sum.)
+#define PTR_EXT_SPP_BLOCK 32
 
 struct TraceArgs {
     const unsigned char* scene;      // one frame block

@@ -57,6 +57,7 @@ constexpr size_t WORDS_BYTES     = WORDS_STATS + 256;
 // coming from hipMalloc.  Every GPU the library runs on holds its own copy (32 MiB) from the moment the library is loaded;
 // all contexts on one GPU share that copy.  Host code never uses the array's name as an address: ptr_create asks for this
 // GPU's address once (hipGetSymbolAddress) and everything below works with that pointer.
+constexpr uint64_t EXT_PARTIAL_MAX_BYTES = (uint64_t)2 << 30;     // the float32 bounce loop's per-block sums (16 B per pixel and block)
 constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t)32 << 20;
 constexpr size_t NOALLOC_QUEUE_OFFSET  = (WORDS_BYTES + 255) / 256 * 256;
 
@@ -90,6 +91,7 @@ struct ptr_ctx {
     DeviceBuffer words;                // see WORDS_*
     unsigned hybrid_calls = 0;         // picks the counter word of the next hybrid call
     bool words_dirty = true;           // counters/stats must be zeroed before the next use
+    DeviceBuffer ext_partial;          // float32 bounce loop, more than one block of samples per pixel: the blocks' sums
     DeviceBuffer out8, out32f;         // staging for ptr_render
     DeviceBuffer tr_in_o, tr_in_d, tr_rgb, tr_el, tr_hit, tr_nrm;   // staging for ptr_trace_batch*
     DeviceBuffer rc_depth, rc_keys, rc_temp;                         // scratch of ptr_rc_reproject*

@@ -669,11 +669,16 @@ __global__ void __launch_bounds__(PTR_BLOCK) render_ext_kernel(RenderArgs a)
 #else
 #define PTR_EXT_OCC
 #endif
-template <bool GEN, bool ONE>
+// how a wave of the float32 form takes its pixels' samples: the one sample there is; all of them, at most one block; ONE block
+// of several (blockIdx.z = frame * blocks + block); all blocks, block by block
+enum { EXT_SPP_ONE = 0, EXT_SPP_ONE_BLOCK = 1, EXT_SPP_SPLIT = 2, EXT_SPP_BLOCKS = 3 };
+template <bool GEN, int SPP>
 __device__ __forceinline__ void render_ext_f32_body(const RenderArgs& a)
 {
     const int lane = threadIdx.x;
-    const int x = blockIdx.x * 8 + (lane & 7), row = blockIdx.y * PTR_TILE_H + (lane >> 3), frame = blockIdx.z;
+    const int x = blockIdx.x * 8 + (lane & 7), row = blockIdx.y * PTR_TILE_H + (lane >> 3);
+    const int frame = SPP == EXT_SPP_SPLIT ? (int)(blockIdx.z / (unsigned)a.ext_blocks) : (int)blockIdx.z;
+    [[maybe_unused]] const int blk = SPP == EXT_SPP_SPLIT ? (int)(blockIdx.z - (unsigned)frame * (unsigned)a.ext_blocks) : 0;
     const unsigned char* block = a.scenes + (uint64_t)(a.first_frame + frame) * a.frame_stride;
     __shared__ float ext_lds[PTR_EXT_LDS_ENTRIES * 640];
     RayStack st;
@@ -703,17 +708,61 @@ __device__ __forceinline__ void render_ext_f32_body(const RenderArgs& a)
     const int y = global_y(a, row);
     if (x >= a.width || row >= a.scan_height) return;            // (after the culling step: every lane speaks for a sphere there)
     V<float> sum{0, 0, 0};
-    const int spp = ONE ? 1 : a.spp;                 // (one sample per pixel: a kernel of its own, as in the float64 form)
-    for (int s = 0; s < spp; s++) {
-        const V<float> d = ext_camera_dir<float>(a, x, y, s);
-        const V<float> c = trace_ext_f32<GEN>(st, block, a, V<float>{0, 0, 0}, d, a.max_depth, cand);
-        sum.x += c.x; sum.y += c.y; sum.z += c.z;
+    if constexpr (SPP == EXT_SPP_SPLIT) {
+        // one block of samples per wave (a tile on a transparent sphere at 256 samples runs for a millisecond: with every
+        // sample of a tile in one wave the launch ends in a long tail of such waves; a block is an eighth of that)
+        const int s0 = blk * PTR_EXT_SPP_BLOCK, s1 = min(s0 + PTR_EXT_SPP_BLOCK, a.spp);
+        for (int s = s0; s < s1; s++) {
+            const V<float> d = ext_camera_dir<float>(a, x, y, s);
+            const V<float> c = trace_ext_f32<GEN>(st, block, a, V<float>{0, 0, 0}, d, a.max_depth, cand);
+            sum.x += c.x; sum.y += c.y; sum.z += c.z;
+        }
+        float4* out = reinterpret_cast<float4*>(a.ext_partial) +
+                      (((uint64_t)frame * (uint64_t)a.ext_blocks + (uint64_t)blk) * (uint64_t)a.scan_height + (uint64_t)row) * (uint64_t)a.width + x;
+        *out = make_float4(sum.x, sum.y, sum.z, 0.0f);
+        return;
+    } else if constexpr (SPP == EXT_SPP_BLOCKS) {
+        // the same sums in the same order, all in this wave (callers that bring no buffer for the blocks' sums)
+        V<float> bs{0, 0, 0};
+        for (int s = 0; s < a.spp; s++) {
+            const V<float> d = ext_camera_dir<float>(a, x, y, s);
+            const V<float> c = trace_ext_f32<GEN>(st, block, a, V<float>{0, 0, 0}, d, a.max_depth, cand);
+            bs.x += c.x; bs.y += c.y; bs.z += c.z;
+            if ((s & (PTR_EXT_SPP_BLOCK - 1)) == PTR_EXT_SPP_BLOCK - 1 || s == a.spp - 1) {
+                sum.x += bs.x; sum.y += bs.y; sum.z += bs.z;
+                bs = V<float>{0, 0, 0};
+            }
+        }
+    } else {
+        const int spp = SPP == EXT_SPP_ONE ? 1 : a.spp;  // (one sample per pixel: a kernel of its own, as in the float64 form)
+        for (int s = 0; s < spp; s++) {
+            const V<float> d = ext_camera_dir<float>(a, x, y, s);
+            const V<float> c = trace_ext_f32<GEN>(st, block, a, V<float>{0, 0, 0}, d, a.max_depth, cand);
+            sum.x += c.x; sum.y += c.y; sum.z += c.z;
+        }
     }
     ext_store<float>(a, frame, x, row, sum);
 }
 
-__global__ void __launch_bounds__(64) PTR_EXT_OCC render_ext_f32_kernel(RenderArgs a) { render_ext_f32_body<false, false>(a); }
-__global__ void __launch_bounds__(64) PTR_EXT_OCC render_ext_f32_one_kernel(RenderArgs a) { render_ext_f32_body<false, true>(a); }
+__global__ void __launch_bounds__(64) PTR_EXT_OCC render_ext_f32_kernel(RenderArgs a) { render_ext_f32_body<false, EXT_SPP_ONE_BLOCK>(a); }
+__global__ void __launch_bounds__(64) PTR_EXT_OCC render_ext_f32_one_kernel(RenderArgs a) { render_ext_f32_body<false, EXT_SPP_ONE>(a); }
+__global__ void __launch_bounds__(64) PTR_EXT_OCC render_ext_f32_split_kernel(RenderArgs a) { render_ext_f32_body<false, EXT_SPP_SPLIT>(a); }
+__global__ void __launch_bounds__(64) PTR_EXT_OCC render_ext_f32_blocks_kernel(RenderArgs a) { render_ext_f32_body<false, EXT_SPP_BLOCKS>(a); }
+
+// the blocks' sums of a pixel, added up in order, averaged and stored (what render_ext_f32_blocks_kernel does in registers)
+__global__ void __launch_bounds__(256) ext_combine_kernel(RenderArgs a)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y, frame = blockIdx.z;
+    if (x >= a.width) return;
+    const uint64_t plane = (uint64_t)a.scan_height * (uint64_t)a.width;
+    const float4* in = reinterpret_cast<const float4*>(a.ext_partial) + (uint64_t)frame * (uint64_t)a.ext_blocks * plane + (uint64_t)row * (uint64_t)a.width + x;
+    V<float> sum{0, 0, 0};
+    for (int b = 0; b < a.ext_blocks; b++) {
+        const float4 v = in[(uint64_t)b * plane];
+        sum.x += v.x; sum.y += v.y; sum.z += v.z;
+    }
+    ext_store<float>(a, frame, x, row, sum);
+}
 #ifndef PTR_EXT_GEN_WAVES
 #define PTR_EXT_GEN_WAVES 7
 #endif
@@ -722,7 +771,9 @@ __global__ void __launch_bounds__(64) PTR_EXT_OCC render_ext_f32_one_kernel(Rend
 #else
 #define PTR_EXT_GEN_OCC
 #endif
-__global__ void __launch_bounds__(64) PTR_EXT_GEN_OCC render_ext_f32_gen_kernel(RenderArgs a) { render_ext_f32_body<true, false>(a); }
+__global__ void __launch_bounds__(64) PTR_EXT_GEN_OCC render_ext_f32_gen_kernel(RenderArgs a) { render_ext_f32_body<true, EXT_SPP_ONE_BLOCK>(a); }
+__global__ void __launch_bounds__(64) PTR_EXT_GEN_OCC render_ext_f32_gen_split_kernel(RenderArgs a) { render_ext_f32_body<true, EXT_SPP_SPLIT>(a); }
+__global__ void __launch_bounds__(64) PTR_EXT_GEN_OCC render_ext_f32_gen_blocks_kernel(RenderArgs a) { render_ext_f32_body<true, EXT_SPP_BLOCKS>(a); }
 
 // ---- the float64 specification in the wave-level form (scenes of spheres) ---------------------------------------------
 // Bit for bit what trace_ext<double> computes - every lane performs the same float64 operations in the same order - but
@@ -1126,8 +1177,18 @@ hipError_t launch_render_ext(const RenderArgs& a, int n_frames, bool f64, bool s
         // one wave per workgroup: the waves' run times differ by an order of magnitude (a tile on a transparent sphere
         // expands a tree of rays), and a one-wave workgroup starts wherever a slot is free
         const dim3 grid1((a.width + 7) / 8, grid.y, n_frames);
-        if (spheres_only) hipLaunchKernelGGL(a.spp == 1 ? render_ext_f32_one_kernel : render_ext_f32_kernel, grid1, dim3(64), 0, s, a);
-        else hipLaunchKernelGGL(render_ext_f32_gen_kernel, grid1, dim3(64), 0, s, a);
+        if (a.spp > PTR_EXT_SPP_BLOCK && a.ext_partial) {
+            // a wave per (tile, block of samples), then the blocks' sums in order
+            const dim3 gridb(grid1.x, grid1.y, (unsigned)n_frames * (unsigned)a.ext_blocks);
+            hipLaunchKernelGGL(spheres_only ? render_ext_f32_split_kernel : render_ext_f32_gen_split_kernel, gridb, dim3(64), 0, s, a);
+            hipLaunchKernelGGL(ext_combine_kernel, dim3((a.width + 255) / 256, a.scan_height, n_frames), dim3(256), 0, s, a);
+        } else if (a.spp > PTR_EXT_SPP_BLOCK) {
+            hipLaunchKernelGGL(spheres_only ? render_ext_f32_blocks_kernel : render_ext_f32_gen_blocks_kernel, grid1, dim3(64), 0, s, a);
+        } else if (spheres_only) {
+            hipLaunchKernelGGL(a.spp == 1 ? render_ext_f32_one_kernel : render_ext_f32_kernel, grid1, dim3(64), 0, s, a);
+        } else {
+            hipLaunchKernelGGL(render_ext_f32_gen_kernel, grid1, dim3(64), 0, s, a);
+        }
     }
     return hipGetLastError();
 }
