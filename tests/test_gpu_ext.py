@@ -292,6 +292,53 @@ def test_float32_form_with_turned_cameras_bands_and_strips(rdr, scenes):
         rdr.set_extension(None, None)
 
 
+def test_float32_sample_blocks_same_bytes_whoever_traces_them(rdr, scenes):
+    """More than 32 samples per pixel, float32 form: a pixel's samples are added up in blocks of 32, the blocks' sums in order
+    (include/ptr.h).  The usual path gives every block of a tile to a wave of its own and adds up afterwards
+    (render_ext_f32_split_kernel + ext_combine_kernel); the entry point that may not allocate has no room for the blocks' sums
+    and keeps them in registers (render_ext_f32_blocks_kernel).  Bytes and float32 colours must be the same either way, for
+    whole frames, bands and cyclic strips, with a last block that is not full (100 = 32 + 32 + 32 + 4), with planes too - and
+    within the float32 tolerance of the float64 specification."""
+    import torch
+    from ptr_amd import synthetic as syn
+    F = ptr_amd.MODE_F32_ONLY
+    stream = torch.cuda.current_stream().cuda_stream
+    try:
+        for planes in (False, True):
+            if planes:
+                soa, pl, ph = syn.planes_scene()
+                rdr.set_camera(None); rdr.set_scene(soa); rdr.set_background(syn.BACKGROUND)
+                rdr.set_extension(pl, ph)
+            else:
+                _load(rdr, scenes["example1"])
+            for (w, h, y0, rows, depth, spp) in ((200, 120, 0, 120, 3, 100), (97, 61, 7, 40, 2, 33), (64, 48, 0, 48, 1, 64)):
+                p = rdr.params(w, h, y0, rows, flags=F, max_depth=depth, spp=spp, seed=11)
+                a8 = torch.zeros((rows, w), dtype=torch.int32, device="cuda"); af = torch.zeros((rows, w, 4), dtype=torch.float32, device="cuda")
+                b8 = torch.zeros_like(a8); bf = torch.zeros_like(af)
+                rdr.render_device(p, 0, 1, a8.data_ptr(), af.data_ptr(), stream=stream)
+                rdr.sync()
+                rdr.render_device_noalloc(p, 0, 1, b8.data_ptr(), bf.data_ptr(), stream=stream)
+                torch.cuda.synchronize()
+                assert torch.equal(a8, b8) and torch.equal(af, bf), (planes, w, h, spp)
+                f64 = rdr.render(w, h, y0, rows, flags=X, max_depth=depth, spp=spp, seed=11)
+                got = a8.cpu().numpy().view(np.uint32).ravel()
+                assert _psnr(got, f64) >= 45.0, (planes, w, h, spp, _psnr(got, f64))
+            # cyclic strips: the parts' rows equal the whole frame's
+            w, h, spp = 120, 72, 70
+            whole = rdr.render(w, h, flags=F, max_depth=2, spp=spp, seed=3).reshape(h, w)
+            for part_no in range(3):
+                part = ptr_amd.StripPart(3, part_no, 8)
+                rows = part.local_rows(h)
+                buf = torch.zeros((rows, w), dtype=torch.int32, device="cuda")
+                p = rdr.params(w, h, 0, rows, flags=F, max_depth=2, spp=spp, seed=3)
+                rdr.render_strips_device(p, part, 0, 1, buf.data_ptr(), stream=stream)
+                torch.cuda.synchronize()
+                assert np.array_equal(buf.cpu().numpy().view(np.uint32), whole[part.global_rows(h)]), (planes, part_no)
+    finally:
+        rdr.set_camera(None)
+        rdr.set_extension(None, None)
+
+
 def test_wave_level_float64_kernel_equals_the_lane_by_lane_one(rdr, scenes):
     """Scenes of spheres take render_ext_f64_kernel (scalar sphere records, tile culling of the camera ray, the shadow loop's
     pair table, square roots and reciprocals by the compiler's own Newton sequences without their range patches); the
