@@ -745,7 +745,12 @@ __device__ __forceinline__ void render_ext_f32_body(const RenderArgs& a)
 }
 
 __global__ void __launch_bounds__(64) PTR_EXT_OCC render_ext_f32_kernel(RenderArgs a) { render_ext_f32_body<false, EXT_SPP_ONE_BLOCK>(a); }
-__global__ void __launch_bounds__(64) PTR_EXT_OCC render_ext_f32_one_kernel(RenderArgs a) { render_ext_f32_body<false, EXT_SPP_ONE>(a); }
+// (its 50 VGPRs and the 5 120 B of LDS would allow 8 waves per SIMD: measured, 2 % slower - 12.22-12.25 against 11.95-12.01 ms per
+// 256 frames at depth 5)
+#ifndef PTR_EXT_ONE_WAVES
+#define PTR_EXT_ONE_WAVES 7
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTR_EXT_ONE_WAVES, PTR_EXT_ONE_WAVES))) render_ext_f32_one_kernel(RenderArgs a) { render_ext_f32_body<false, EXT_SPP_ONE>(a); }
 __global__ void __launch_bounds__(64) PTR_EXT_OCC render_ext_f32_split_kernel(RenderArgs a) { render_ext_f32_body<false, EXT_SPP_SPLIT>(a); }
 __global__ void __launch_bounds__(64) PTR_EXT_OCC render_ext_f32_blocks_kernel(RenderArgs a) { render_ext_f32_body<false, EXT_SPP_BLOCKS>(a); }
 
@@ -806,8 +811,11 @@ __device__ __forceinline__ double sqrt_w(double x, bool want)
     return __builtin_sqrt(x);
 }
 
+// Waiting rays of a lane in LDS (4 864 B per wave and entry) x waves per SIMD, final kernel, 64 frames of the example scene at
+// 1080p, A/B on one box: 2 x 4 6.85-6.88 ms at depth 5 / 4.84 at depth 3; 1 x 5 6.65-6.67 / 4.57-4.60 (the fifth wave is worth
+// more than the second entry; several samples per pixel: no difference); bytes identical.
 #ifndef PTR_EXT64_LDS_ENTRIES
-#define PTR_EXT64_LDS_ENTRIES 2
+#define PTR_EXT64_LDS_ENTRIES 1
 #endif
 struct RayStack64 {
     double* base;      // this lane's first double in LDS: 9 doubles per entry, 512 bytes apart
@@ -1105,7 +1113,7 @@ __device__ V<double> trace_ext_f64w(RayStack64& stack, const unsigned char* bloc
 }
 
 #ifndef PTR_EXT64_WAVES
-#define PTR_EXT64_WAVES 4
+#define PTR_EXT64_WAVES 5
 #endif
 // ONE: one sample per pixel, a kernel of its own (the sample loop keeps the camera's 30 SGPRs alive through the whole ray tree:
 // with it the kernel spills scalar registers)
