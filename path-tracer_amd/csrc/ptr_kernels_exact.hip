@@ -221,17 +221,29 @@ __device__ V3 trace_exact_wide(const FrameView& fv, V3 o, V3 d)
     const int n = fv.h->n, lane = threadIdx.x & 63;
     double tnear = PTR_INFINITY;
     int element = 0x7fffffff;
-    for (int i = lane; i < n; i += 64) {
-        const SphereG64 s = fv.g64[i];
-        double lx = s.cx - o.x, ly = s.cy - o.y, lz = s.cz - o.z;
-        double tca = lx * d.x + ly * d.y + lz * d.z;
-        if (tca < 0) continue;
-        double d2 = (lx * lx + ly * ly + lz * lz) - tca * tca;
-        if (d2 > s.r2) continue;
-        double thc = __builtin_sqrt(s.r2 - d2);
-        double t0 = tca - thc, t1 = tca + thc;
-        if (t0 < 0) t0 = t1;
-        if (t0 < tnear) { tnear = t0; element = i; }
+    // WIDE_UNROLL records per lane and trip, all requested before the first is used: a wave spends its time waiting for
+    // these loads (one record per trip: 1.0 ms for the 13 000 re-traced pixels of a 1080p frame of BASELINE config 5), and
+    // nothing else hides them.  The tests run in element order as before (a lane's strict '<' scan sees increasing i).
+    constexpr int WIDE_UNROLL = 4;
+    for (int i0 = lane; i0 < n; i0 += 64 * WIDE_UNROLL) {
+        SphereG64 rec[WIDE_UNROLL];
+#pragma unroll
+        for (int u = 0; u < WIDE_UNROLL; u++) { const int i = i0 + 64 * u; rec[u] = fv.g64[i < n ? i : n - 1]; }
+#pragma unroll
+        for (int u = 0; u < WIDE_UNROLL; u++) {
+            const int i = i0 + 64 * u;
+            if (i >= n) continue;
+            const SphereG64 s = rec[u];
+            double lx = s.cx - o.x, ly = s.cy - o.y, lz = s.cz - o.z;
+            double tca = lx * d.x + ly * d.y + lz * d.z;
+            if (tca < 0) continue;
+            double d2 = (lx * lx + ly * ly + lz * lz) - tca * tca;
+            if (d2 > s.r2) continue;
+            double thc = __builtin_sqrt(s.r2 - d2);
+            double t0 = tca - thc, t1 = tca + thc;
+            if (t0 < 0) t0 = t1;
+            if (t0 < tnear) { tnear = t0; element = i; }
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -257,16 +269,22 @@ __device__ V3 trace_exact_wide(const FrameView& fv, V3 o, V3 d)
         V3 L{li.cx - P.x, li.cy - P.y, li.cz - P.z};
         normalize_js(L);
         double tr = 1.0;
-        for (int j0 = 0; j0 < n; j0 += 64) {                 // wave-uniform trip count
-            const int j = j0 + lane;
-            bool hit = false;
-            if (j < n && j != i) {
-                const SphereG64 s = fv.g64[j];
-                double lx = s.cx - so.x, ly = s.cy - so.y, lz = s.cz - so.z;
-                double tca = lx * L.x + ly * L.y + lz * L.z;
-                if (!(tca < 0)) {
-                    double d2 = (lx * lx + ly * ly + lz * lz) - tca * tca;
-                    hit = !(d2 > s.r2);
+        for (int j0 = 0; j0 < n; j0 += 64 * WIDE_UNROLL) {   // wave-uniform trip count
+            SphereG64 rec[WIDE_UNROLL];
+#pragma unroll
+            for (int u = 0; u < WIDE_UNROLL; u++) { const int j = j0 + 64 * u + lane; rec[u] = fv.g64[j < n ? j : n - 1]; }
+            bool hit = false;                                 // (any hit blocks the light, whichever element it is: RayTracer.js:77-81)
+#pragma unroll
+            for (int u = 0; u < WIDE_UNROLL; u++) {
+                const int j = j0 + 64 * u + lane;
+                if (j < n && j != i) {
+                    const SphereG64 s = rec[u];
+                    double lx = s.cx - so.x, ly = s.cy - so.y, lz = s.cz - so.z;
+                    double tca = lx * L.x + ly * L.y + lz * L.z;
+                    if (!(tca < 0)) {
+                        double d2 = (lx * lx + ly * ly + lz * lz) - tca * tca;
+                        hit |= !(d2 > s.r2);
+                    }
                 }
             }
             if (__builtin_amdgcn_ballot_w64(hit) != 0ull) { tr = 0.0; break; }
@@ -285,7 +303,10 @@ __device__ V3 trace_exact_wide(const FrameView& fv, V3 o, V3 d)
 // synchronises between the two kernels.  kind 0 (blockIdx.y == 0): re-trace the pixel from scratch;
 // kind 1: the nearest element is certain and so are some of the shadow verdicts (qinfo), only the
 // shading is redone in float64 (entries stored from the back of the sub-queue).
-template <int KIND>        // one kernel per kind: the shading-only one needs far fewer registers than the full re-trace
+// one kernel per kind: the shading-only one needs far fewer registers than the full re-trace; WIDE: the full re-trace of a scene
+// of many spheres (a wave per pixel, several records in flight per lane: 121 VGPRs against 93), a kernel of its own so that
+// the few-sphere one keeps its five waves per SIMD
+template <int KIND, bool WIDE>
 __global__ void __launch_bounds__(PTR_BLOCK) retrace_exact_kernel(RenderArgs a)
 {
     // The grid always has PTR_MAX_QUEUES x (parts1 + parts0) workgroups: every counter of the OTHER set is zeroed for the
@@ -305,7 +326,7 @@ __global__ void __launch_bounds__(PTR_BLOCK) retrace_exact_kernel(RenderArgs a)
     const uint32_t* queue = a.queue + (uint64_t)sub * a.queue_capacity;
     const uint32_t* qinfo = a.qinfo + (a.qinfo_packed ? 1u : 2u) * (uint64_t)sub * a.queue_capacity;
     const uint64_t frame_px = (uint64_t)a.width * (uint64_t)a.scan_height;
-    if (KIND == 0 && a.n >= PTR_WIDE_RETRACE_MIN) {
+    if constexpr (KIND == 0 && WIDE) {
         // many spheres: one wave per queued pixel (trace_exact_wide), waves of all the sub-queue's workgroups take turns
         const uint32_t waves = (blockDim.x >> 6) * nparts;
         for (uint32_t q = part * (blockDim.x >> 6) + (threadIdx.x >> 6); q < count; q += waves) {
@@ -412,8 +433,9 @@ hipError_t launch_render_exact(const RenderArgs& a, int n_frames, bool stats, hi
 hipError_t launch_retrace_exact(const RenderArgs& a0, int parts1, int parts0, hipStream_t s)
 {
     const RenderArgs& a = a0;
-    hipLaunchKernelGGL(retrace_exact_kernel<0>, dim3(PTR_MAX_QUEUES, parts0, 1), dim3(PTR_BLOCK), 0, s, a);
-    if (parts1 > 0) hipLaunchKernelGGL(retrace_exact_kernel<1>, dim3(PTR_MAX_QUEUES, parts1, 1), dim3(PTR_BLOCK), 0, s, a);   // (0: no shading-only entries in this mode)
+    if (a.n >= PTR_WIDE_RETRACE_MIN) hipLaunchKernelGGL((retrace_exact_kernel<0, true>), dim3(PTR_MAX_QUEUES, parts0, 1), dim3(PTR_BLOCK), 0, s, a);
+    else hipLaunchKernelGGL((retrace_exact_kernel<0, false>), dim3(PTR_MAX_QUEUES, parts0, 1), dim3(PTR_BLOCK), 0, s, a);
+    if (parts1 > 0) hipLaunchKernelGGL((retrace_exact_kernel<1, false>), dim3(PTR_MAX_QUEUES, parts1, 1), dim3(PTR_BLOCK), 0, s, a);   // (0: no shading-only entries in this mode)
     return hipGetLastError();
 }
 

@@ -95,8 +95,13 @@ __device__ __forceinline__ bool any_lane(bool c) { return ballot(c) != 0ull; }
 
 // SMALL: few spheres — the level-1 records come through scalar loads into SGPRs instead of LDS (no staging,
 // no barriers), one sphere per level-1 compare.
+#ifdef PTR_MANY_WAVES
+#define PTR_MANY_OCC __attribute__((amdgpu_waves_per_eu(PTR_MANY_WAVES, PTR_MANY_WAVES)))
+#else
+#define PTR_MANY_OCC
+#endif
 template <bool HYBRID, bool DBG, bool SMALL>
-__global__ void __launch_bounds__(PTR_BLOCK) render_many_kernel(RenderArgs a)
+__global__ void __launch_bounds__(PTR_BLOCK) PTR_MANY_OCC render_many_kernel(RenderArgs a)
 {
     constexpr int PPL = PTR_MANY_PPL, NP = PPL / 2;      // pixel p = 2 * pair + component
     constexpr bool BOUNDS = HYBRID || DBG;                // the error-bound arithmetic has a consumer
