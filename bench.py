@@ -48,12 +48,12 @@ PEAK_HBM_GBPS = 8000.0
 # correction of the guide applied: FETCH_SIZE counts 64 B per 128-B request -> x 2).  Counters cannot be read from
 # inside this process, so the per-launch figure reported below is this profiled rate times the launch's pixels
 # (reported as "traffic", with "traffic_source" saying so).
-PROFILED_HBM_BYTES_PER_PIXEL = {"tolerant": (2092250.0 * 1024 + 2 * 4109.98 * 1024) / (256 * 1920 * 1080),
-                                "exact": (2306760.0 * 1024 + 2 * 5768.03 * 1024) / (256 * 1920 * 1080)}
+PROFILED_HBM_BYTES_PER_PIXEL = {"tolerant": (2092070.0 * 1024 + 2 * 4113.06 * 1024) / (256 * 1920 * 1080),
+                                "exact": (2306920.0 * 1024 + 2 * 5707.05 * 1024) / (256 * 1920 * 1080)}
 # ... and of one reprojection pass over the 1920 x 1080 x 4 cache on one GPU (same profile: rc_clear + rc_project + hipCUB's five
-# radix-sort kernels + rc_resolve; FETCH_SIZE 11.5 + 129 620 + 5 x 33 015.1 + 328 315 KB, x 2; WRITE_SIZE 24 840 + 209 808 +
-# 5 x 60 042.1 + 142 813 KB): 1.97 GB against 0.39 GB algorithmic
-PROFILED_RC_BYTES_PER_PASS = int((2 * (11.5 + 129620 + 5 * 33015.1 + 328315) + (24840 + 209808 + 5 * 60042.1 + 142813)) * 1024)
+# radix-sort kernels + rc_resolve; FETCH_SIZE 11.5 + 129 619 + 5 x 33 011.6 + 328 372 KB, x 2; WRITE_SIZE 24 840 + 209 808 +
+# 5 x 60 016.5 + 142 818 KB): 1.97 GB against 0.39 GB algorithmic
+PROFILED_RC_BYTES_PER_PASS = int((2 * (11.5 + 129619 + 5 * 33011.6 + 328372) + (24840 + 209808 + 5 * 60016.5 + 142818)) * 1024)
 
 
 def example1_soa():
