@@ -362,3 +362,36 @@ def test_library_gather_on_one_gpu(scenes):
         assert np.array_equal(ptr_amd.render_multi([a], w, h).reshape(h, w), want[0])
     finally:
         a.close(); b.close()
+
+
+def test_host_buffer_copies_pageable_pinned_and_sizes(scenes):
+    """ptr_render's way back to the host: a page-locked destination takes one DMA, a pageable one is filled through the
+    context's two page-locked halves in pieces of at most 1 MiB (copy_to_host).  Same bytes as the device-buffer entry for
+    frames below the staging threshold, of exactly one piece, of several pieces with a ragged last one, for the float32 frame
+    (16 bytes per pixel: many pieces) and for a destination that does not start on a 16-byte boundary."""
+    import ctypes as C
+    torch = pytest.importorskip("torch")
+    sc = scenes["example1"]
+    r = ptr_amd.Renderer(0)
+    try:
+        r.set_elements(sc["elements"]); r.set_background(sc["background"])
+        for (w, h) in ((64, 48), (256, 256), (512, 512), (1920, 1080), (1001, 517)):
+            p = r.params(w, h, flags=0)
+            dev8 = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+            devf = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+            r.render_device(p, 0, 1, dev8.data_ptr(), devf.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            want8 = dev8.cpu().numpy().view(np.uint32).ravel(); wantf = devf.cpu().numpy()
+            got8, gotf = r.render(w, h, flags=0, want_f32=True)                       # pageable numpy buffers
+            assert np.array_equal(got8, want8) and np.array_equal(gotf, wantf), (w, h)
+            pin8 = torch.zeros(w * h, dtype=torch.int32).pin_memory()                 # page-locked: the direct copy
+            r._check(r._L.ptr_render(r._h, C.byref(p), C.cast(pin8.data_ptr(), C.POINTER(C.c_uint32)), None))
+            assert np.array_equal(pin8.numpy().view(np.uint32), want8), (w, h)
+            raw = np.zeros(w * h * 4 + 64, dtype=np.uint8)                            # pageable, 4 bytes off a 16-byte boundary
+            off = (-raw.ctypes.data) % 16 + 4
+            view = raw[off:off + w * h * 4]
+            r._check(r._L.ptr_render(r._h, C.byref(p), C.cast(view.ctypes.data, C.POINTER(C.c_uint32)), None))
+            assert np.array_equal(view.view(np.uint32), want8), (w, h)
+            assert not raw[:off].any() and not raw[off + w * h * 4:].any()
+    finally:
+        r.close()
