@@ -203,7 +203,11 @@ struct RenderArgs {
 // The float32 forms of the extension modes add a pixel's samples up block by block: the sum of every PTR_EXT_SPP_BLOCK
 // consecutive samples first, then the blocks' sums in order.  With at most that many samples it is the plain sum.  (The float64
 // form is the specification: one running sum.)
+// (Block size, A/B on one box with tools/config3_time.py, configs[3] on one GPU / configs[2]: 16 samples 15.33-15.38 / 0.992 ms,
+// 32 samples 15.22-15.25 / 1.00 ms, 64 samples 15.73-15.75 / 1.05-1.06 ms.)
+#ifndef PTR_EXT_SPP_BLOCK
 #define PTR_EXT_SPP_BLOCK 32
+#endif
 
 struct TraceArgs {
     const unsigned char* scene;      // one frame block
