@@ -25,7 +25,9 @@
 #ifndef PTR_FAST_PPL_TOL
 #define PTR_FAST_PPL_TOL 4        // PTR_MODE_TOLERANT: 4 pixels per lane (wave tile 32 x 8) at 5 waves per SIMD (96 VGPRs): measured -3.4 %
 #endif                            //   against 3 pixels at 6 waves (the per-wave work - culling, cones, scalar bookkeeping - is shared by more pixels)
+#ifndef PTR_FAST_WAVES_WIDE
 #define PTR_FAST_WAVES_WIDE 5
+#endif
 #define PTR_MAX_QUEUES 1024       // sub-queues of the hybrid mode's re-trace queue
 #define PTR_MAX_PAIR_LIGHTS 64     // lights with a shadow pre-filter table (more lights: no culling for them)
 #define PTR_FAST_MAX_SPHERES 12    // up to this many spheres: ptr_kernels_fast.hip; more: ptr_kernels_many.hip (measured
