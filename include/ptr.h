@@ -98,7 +98,9 @@ typedef struct ptr_ctx ptr_ctx;
  * throughput form (tolerance: see tests/test_gpu_ext.py - PSNR > 50 dB, but single pixels on discontinuities and their
  * mirror images can be off by more than 1/255, which is why it is not the default; its samples are added up in blocks of 32
  * consecutive samples, then the blocks' sums in order - with at most 32 samples that is the plain sum - so that a pixel's
- * blocks can be traced by different waves: same bytes whether they are or not); PTR_QUIRK_ROW_SHIFT is rejected.  */
+ * blocks can be traced by different waves: same bytes whether they are or not - the library does so when the blocks' sums
+ * of the call, 16 bytes per pixel and block, fit in 2 GiB of device memory that the context then holds, and never in
+ * ptr_render_device_noalloc); PTR_QUIRK_ROW_SHIFT is rejected.  */
 #define PTR_MAX_DEPTH_LIMIT 16
 #define PTR_MAX_SPP         65536
 typedef struct ptr_params {
