@@ -339,7 +339,8 @@ static napi_value js_render_into(napi_env env, napi_callback_info info)
 typedef struct {
     ptr_ctx *ctx;
     ptr_params p;
-    uint32_t *pixels;
+    uint32_t *pixels;           /* the result ArrayBuffer's own memory: the frame is copied off the GPU straight into it */
+    napi_ref result_ref;        /* ... and this keeps that ArrayBuffer alive until the promise is settled */
     int rc;
     char err[512];
     napi_deferred deferred;
@@ -364,10 +365,7 @@ static void render_complete(napi_env env, napi_status status, void *data)
     render_job *j = (render_job *)data;
     napi_value result;
     if (status == napi_ok && j->rc == PTR_OK) {
-        void *dst = NULL;
-        size_t bytes = (size_t)j->p.width * (size_t)j->p.scan_height * 4;
-        if (napi_create_arraybuffer(env, bytes, &dst, &result) == napi_ok) {
-            memcpy(dst, j->pixels, bytes);
+        if (napi_get_reference_value(env, j->result_ref, &result) == napi_ok && result) {
             napi_resolve_deferred(env, j->deferred, result);
         } else {
             napi_value msg, err;
@@ -387,8 +385,8 @@ static void render_complete(napi_env env, napi_status status, void *data)
         j->cell->closing = 0;
     }
     napi_delete_reference(env, j->handle_ref);
+    napi_delete_reference(env, j->result_ref);
     napi_delete_async_work(env, j->work);
-    free(j->pixels);
     free(j);
 }
 
@@ -403,15 +401,25 @@ static napi_value js_render_async(napi_env env, napi_callback_info info)
     j->ctx = ctx;
     if (napi_get_value_external(env, argv[0], (void **)&j->cell) != napi_ok || !j->cell) { free(j); return NULL; }
     if (!read_params(env, argv + 1, &j->p) || !check_frame_size(env, &j->p)) { free(j); return NULL; }
-    j->pixels = (uint32_t *)malloc((size_t)j->p.width * (size_t)j->p.scan_height * 4);
-    if (!j->pixels) { free(j); napi_throw_error(env, NULL, "out of memory"); return NULL; }
+    /* the caller's ArrayBuffer is made here, on the JavaScript thread, and filled by the job (its memory does not move) */
+    napi_value result_buf;
+    void *data = NULL;
+    if (napi_create_arraybuffer(env, (size_t)j->p.width * (size_t)j->p.scan_height * 4, &data, &result_buf) != napi_ok ||
+        napi_create_reference(env, result_buf, 1, &j->result_ref) != napi_ok) {
+        free(j);
+        napi_throw_error(env, NULL, "out of memory");
+        return NULL;
+    }
+    j->pixels = (uint32_t *)data;
     napi_value promise, name;
     if (napi_create_promise(env, &j->deferred, &promise) != napi_ok ||
         napi_create_reference(env, argv[0], 1, &j->handle_ref) != napi_ok ||
         napi_create_string_utf8(env, "ptr_render", NAPI_AUTO_LENGTH, &name) != napi_ok ||
         napi_create_async_work(env, NULL, name, render_execute, render_complete, j, &j->work) != napi_ok ||
         napi_queue_async_work(env, j->work) != napi_ok) {
-        free(j->pixels); free(j);
+        napi_delete_reference(env, j->result_ref);
+        if (j->handle_ref) napi_delete_reference(env, j->handle_ref);
+        free(j);
         napi_throw_error(env, NULL, "could not start the async render");
         return NULL;
     }
