@@ -473,10 +473,11 @@ def main():
     # that follow, so that the K timed steps measure the steady state (reported as `pre_warm_s`).
     PRE_WARM_S = 0.25
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < PRE_WARM_S:
+    while time.perf_counter() - t_pre < PRE_WARM_S:           # (by the clock: every rank for itself, hence without the exchange)
         for _ in range(4):
-            step()
+            step(gather=False)
         torch.cuda.synchronize()
+    fence()
     for _ in range(args.warmup):
         step()
     fence()
