@@ -262,7 +262,61 @@ def rc_reprojection_line(ptr_amd, torch, dist, rdr, world, rank, backend, librar
                          "note": "algorithmic bytes of the whole cache / the wall time of a pass (all ranks, exchange included)"}}
 
 
+def exchange_probe_child(uid_hex, rank, world, device):
+    """Child process of one rank (N > 1): the library's communicator and one small checked gather, away from the bench's own
+    process - a collective that never returns then hangs THIS process, which the parent ends, instead of the bench."""
+    import torch
+    import ptr_amd
+    torch.cuda.set_device(device)
+    stream = torch.cuda.Stream()
+    rdr = ptr_amd.Renderer(device)
+    rdr.set_scene(example1_soa()); rdr.set_background(np.array([2.0, 2.0, 2.0]))
+    rdr.comm_init_rank(bytes.fromhex(uid_hex), rank, world)
+    w, h = 512, 256
+    part = ptr_amd.StripPart(world, rank, STRIP)
+    rows, max_rows = part.local_rows(h), ptr_amd.StripPart(world, 0, STRIP).local_rows(h)
+    local = torch.zeros((1, max_rows, w), dtype=torch.int32, device="cuda")
+    full = torch.zeros((1, h, w), dtype=torch.int32, device="cuda") if rank == 0 else None
+    rdr.render_strips_device(rdr.params(w, h, 0, rows, flags=0), part, 0, 1, local.data_ptr(), stream=stream.cuda_stream,
+                             frame_stride_px=max_rows * w)
+    rdr.gather_strips_device(w, h, STRIP, 1, local.data_ptr(), full.data_ptr() if rank == 0 else None, root=0,
+                             frame_stride_px=max_rows * w, stream=stream.cuda_stream)
+    torch.cuda.synchronize()
+    good = True
+    if rank == 0:
+        whole = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+        rdr.render_device(rdr.params(w, h, flags=0), 0, 1, whole.data_ptr(), stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+        good = bool(torch.equal(full[0], whole))
+    print("probe ok" if good else "probe: the gathered frame differs", flush=True)
+    os._exit(0 if good else 2)                     # (no teardown: a communicator's destructor is one more collective)
+
+
+def exchange_probe(uid, rank, world, device, seconds):
+    """-> True if this rank's child process finished the probe in time"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--probe", bytes(uid).hex(), str(rank), str(world), str(device)]
+    try:
+        child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    except OSError as e:
+        print(f"rank {rank}: could not start the exchange probe ({e})", file=sys.stderr)
+        return False
+    try:
+        out, _ = child.communicate(timeout=seconds)
+    except subprocess.TimeoutExpired:
+        child.kill()
+        child.communicate()
+        print(f"rank {rank}: the exchange probe did not return within {seconds} s (ended)", file=sys.stderr)
+        return False
+    if child.returncode != 0:
+        print(f"rank {rank}: the exchange probe failed (exit {child.returncode}): {out.strip()[-400:]}", file=sys.stderr)
+    return child.returncode == 0
+
+
 def main():
+    if len(sys.argv) >= 6 and sys.argv[1] == "--probe":
+        exchange_probe_child(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -361,24 +415,56 @@ def main():
         watchdog = threading.Timer(WATCHDOG_S, _stuck)
         watchdog.daemon = True
         watchdog.start()
-        ok = 1
-        try:
+        coll_dev = "cuda" if backend == "nccl" else "cpu"
+
+        def agreed(ok):                          # every rank learns whether every rank is fine
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=coll_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+
+        def shared_id():                         # (always the same collectives on every rank, whatever rank 0 runs into)
             uid = torch.zeros(128, dtype=torch.uint8)
+            fine = True
             if rank == 0:
-                uid = torch.frombuffer(bytearray(rdr.comm_unique_id()), dtype=torch.uint8).clone()
-            uid = uid.cuda() if backend == "nccl" else uid
+                try:
+                    uid = torch.frombuffer(bytearray(rdr.comm_unique_id()), dtype=torch.uint8).clone()
+                except Exception as e:           # noqa: BLE001
+                    print(f"rank 0: no RCCL id from the library ({e})", file=sys.stderr)
+                    fine = False
+            uid = uid.to(coll_dev)
             dist.broadcast(uid, src=0)
-            if backend != "nccl":
-                raise RuntimeError("rehearsal backend: ranks may share a GPU, which RCCL refuses")
-            if os.environ.get("PTR_BENCH_GATHER") == "torch":
-                raise RuntimeError("PTR_BENCH_GATHER=torch")
-            rdr.comm_init_rank(bytes(uid.cpu().numpy().tobytes()), rank, world)
-        except Exception as e:                   # noqa: BLE001 - whatever went wrong, every rank has to learn of it
-            ok = 0
-            print(f"rank {rank}: library communicator not available ({e}); gathering with torch.distributed", file=sys.stderr)
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        gather_mode = "library" if int(flag.item()) == 1 else "torch"
+            return bytes(uid.cpu().numpy().tobytes()) if agreed(fine) else None
+
+        why = None
+        if backend != "nccl" and os.environ.get("PTR_BENCH_PROBE") != "force":
+            why = "rehearsal backend: ranks may share a GPU, which RCCL refuses"
+        elif os.environ.get("PTR_BENCH_GATHER") == "torch":
+            why = "PTR_BENCH_GATHER=torch"
+        use_library = agreed(why is None)
+        if use_library:
+            # first in a child process per rank: communicator + one small checked gather.  If that hangs or fails, the child is
+            # ended and this process never touches the library's exchange (PTR_BENCH_PROBE=0 skips the probe).
+            if os.environ.get("PTR_BENCH_PROBE") != "0":
+                pid = shared_id()
+                probe_ok = pid is not None and exchange_probe(pid, rank, world, local_rank,
+                                                              int(os.environ.get("PTR_BENCH_PROBE_S", "120")))
+                use_library = agreed(probe_ok)
+                if not use_library:
+                    why = "the library's exchange did not pass its probe in a child process"
+        if use_library:
+            uid = shared_id()
+            ok = uid is not None
+            if ok:
+                try:
+                    rdr.comm_init_rank(uid, rank, world)
+                except Exception as e:           # noqa: BLE001 - whatever went wrong, every rank has to learn of it
+                    ok = False
+                    why = str(e)
+            use_library = agreed(ok)
+        if not use_library:
+            print(f"rank {rank}: library communicator not used ({why or 'another rank reported a failure'}); "
+                  f"gathering with torch.distributed", file=sys.stderr)
+        gather_mode = "library" if use_library else "torch"
         comm_stream = torch.cuda.Stream()
     render_stream = torch.cuda.current_stream()
     rendered = [torch.cuda.Event() for _ in range(n_buf)]
