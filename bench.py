@@ -288,6 +288,23 @@ def exchange_probe_child(uid_hex, rank, world, device):
         rdr.render_device(rdr.params(w, h, flags=0), 0, 1, whole.data_ptr(), stream=stream.cuda_stream)
         torch.cuda.synchronize()
         good = bool(torch.equal(full[0], whole))
+    # ... and the other collective the library uses (ncclAllGather, in place, in a group): a small cache's reprojection split over
+    # the ranks (the bench checks its result itself later; here it only has to come back)
+    w2, h2 = 96, 64
+    n2, cells2 = w2 * h2 * 4, (w2 + 2) * (h2 + 2)
+    rng = np.random.default_rng(7)
+    hits = np.stack([rng.uniform(-30, 30, n2), rng.uniform(-6, 14, n2), rng.uniform(-60, -8, n2)], axis=1)
+    rec = np.fromfile(os.path.join(ROOT, "tests", "golden", "rc", "reproject_move_96x64.f64"), count=35)
+    cam = rdr.rc_camera(rec[0:3], rec[3:19], rec[19:35].copy(), w2, h2)
+    lo, hi = n2 * rank // world, n2 * (rank + 1) // world
+    d_hit = torch.from_numpy(hits[lo:hi]).cuda()
+    d_age = torch.zeros(hi - lo, dtype=torch.float64, device="cuda")
+    d_ip = torch.empty(hi - lo, dtype=torch.int32, device="cuda")
+    d_pel = torch.full((cells2,), -1, dtype=torch.int32, device="cuda")
+    d_pdep = torch.full((cells2,), 1e6, dtype=torch.float64, device="cuda")
+    rdr.rc_reproject_multi_device(cam, hi - lo, lo, d_hit.data_ptr(), d_age.data_ptr(), d_ip.data_ptr(), d_pel.data_ptr(),
+                                  d_pdep.data_ptr(), stream=stream.cuda_stream)
+    torch.cuda.synchronize()
     print("probe ok" if good else "probe: the gathered frame differs", flush=True)
     os._exit(0 if good else 2)                     # (no teardown: a communicator's destructor is one more collective)
 
