@@ -25,7 +25,9 @@
 
 namespace ptr {
 
+#ifndef PTR_MANY_CHUNK
 #define PTR_MANY_CHUNK 1024          // 16 KB of LDS per workgroup
+#endif
 #define PTR_MANY_PPL   4
 #define PTR_MANY_TILE  32            // workgroup tile 32 x 32: 2 x 2 waves of 16 x 16, 2 x 2 sub-tiles of 8 x 8 per lane
 
