@@ -59,6 +59,14 @@ async function main() {
               from: k => [0.4 * k, 0.3, 2], to: k => [0, 0, -20] },
             { name: 'onespp_ratio3_60x40', w: 60, h: 40, ratio: 3, frames: 5, seed: 25, method: 'nextFrame1SPP',
               from: k => [0, 0.5 * k, 3 - 0.5 * k], to: k => [0.5 * k, 0, -20] },
+            // odd width and height (the pixel the candidate loops leave behind depends on the height's parity, Driver.js:813-814)
+            { name: 'odd_75x45', w: 75, h: 45, ratio: 4, frames: 5, seed: 26, from: k => [-0.6 * k, 0.5 + 0.2 * k, 2 + 0.3 * k], to: k => [0.4 * k, 0, -20] },
+            // many frames at ratio 2 with a camera that swings back and forth: the cache's pages fill up and allocCacheItem has to
+            // clear the oldest item of a page (:283-297)
+            { name: 'long_64x40', w: 64, h: 40, ratio: 2, frames: 16, seed: 27,
+              from: k => [4 * Math.sin(0.9 * k), 1 + Math.cos(0.7 * k), 4 + 2 * Math.cos(0.9 * k)], to: k => [3 * Math.sin(1.3 * k), 0, -20] },
+            { name: 'onespp_odd_45x27', w: 45, h: 27, ratio: 2, frames: 4, seed: 28, method: 'nextFrame1SPP',
+              from: k => [0.3 * k, 0.2 * k, 2.5], to: k => [0, 0.2 * k, -20] },
         ];
         for (const cs of cases) {
             const scene = new Scene2();

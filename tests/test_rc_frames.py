@@ -128,13 +128,13 @@ def test_golden_frames_are_complete(golden_dir):
         assert frames.shape[2] == m["width"] * m["height"], name
         assert np.isfinite(rec[:, 68:74]).all(), name
         n += m["frames"]
-    assert n == 13
+    assert n == 34
     n = 0
     for name, m, scene, rec, frames in frame_cases(golden_dir, "nextFrame1SPP"):
         assert frames.shape[2] == m["width"] * m["height"], name
         assert np.isfinite(rec[:, 68:74]).all(), name
         n += m["frames"]
-    assert n == 9
+    assert n == 13
 
 
 @pytest.mark.gpu
