@@ -363,7 +363,7 @@ async function gpuTests() {
             Math.random = realRandom;
         }
     });
-    test('RenderCacheDriver: the resident frame loop leaves the same cache, grid and frames as the host walks (odd sizes, a frame that requests every pixel, a restart, other tunables)', () => {
+    test('RenderCacheDriver: the resident frame loop leaves the same cache, grid and frames as the host walks (odd sizes, a frame that requests every pixel, a restart, other tunables, caches small enough that full pages reuse their oldest item)', () => {
         // no reference output exists at these sizes: the host form of the driver (bit-identical to the reference on the goldens
         // above) is the comparator; every array of the state is compared after every frame
         const idx = JSON.parse(fs.readFileSync(path.join(golden, 'rc', 'frames_index.json')));
@@ -372,17 +372,24 @@ async function gpuTests() {
         const realRandom = Math.random;
         const arrays = ['itemPixel', 'itemHit', 'itemAge', 'itemRgb', 'pixelElement', 'pixelDepth', 'pixelRgb', 'pixelPriority', 'pixelSample'];
         try {
-            for (const [w, h, ratio, nframes, tweak] of [[151, 97, 16, 7], [64, 33, 1, 4], [320, 200, 8, 6], [37, 2, 2, 5],
+            // cacheFactor (Driver.js:81-88 reads it in prepare) below 4: the cache is as large as the frame or smaller, its pages fill
+            // up and allocCacheItem reuses the oldest item of a page (:283-297) - on the GPU rc_alloc's second branch
+            for (const [w, h, ratio, nframes, tweak, before] of [[151, 97, 16, 7], [64, 33, 1, 4], [320, 200, 8, 6], [37, 2, 2, 5],
                     [96, 40, 8, 5, { ageFactor: 2, interpolationZero: 5, interpolationRandom: 1, priorityMax: 100, depthThreshold: 60 }],
-                    [50, 50, 3, 4, { ageFactor: 3, priorityMax: 7 }]]) {
+                    [50, 50, 3, 4, { ageFactor: 3, priorityMax: 7 }],
+                    [64, 40, 2, 10, null, { cacheFactor: 1 }], [48, 32, 1, 6, { ageFactor: 2 }, { cacheFactor: 0.5 }]]) {
                 const drvs = [false, true].map(resident => {
                     const rt = new RayTracer(new Vector3(...desc.background), sceneFrom(desc), undefined, { mode: 'exact' });
                     const cam = new RcCamera(w, h), drv = new RenderCacheDriver(rt, cam, ratio, { resident });
+                    Object.assign(drv, before || {});
                     drv.prepare(false);
                     Object.assign(drv, tweak || {});                                     // the reference's tunables are plain fields
                     return { rt, cam, drv };
                 });
                 const px = w * h, a = new Uint32Array(px), b = new Uint32Array(px);
+                let reused = 0;                                                          // full pages met by the host walk
+                const clearItem = drvs[0].drv._clearItem;
+                drvs[0].drv._clearItem = function (i) { reused++; return clearItem.call(this, i); };
                 for (let k = 0; k < nframes; k++) {
                     const frameIndex = (k === 4 && w === 151) ? 0 : k;                   // a restart in the middle of one sequence
                     const o = (k % m.frames) * m.doubles_per_frame, tag = `${w}x${h} ratio ${ratio} frame ${k}`;
@@ -409,6 +416,7 @@ async function gpuTests() {
                         assert.strictEqual(bad, -1, `${tag} ${name}[${bad}]: ${x[bad]} !== ${y[bad]}`);
                     }
                 }
+                if (before) assert.ok(reused > 100, `${w}x${h} cacheFactor ${before.cacheFactor}: only ${reused} items reused`);
                 for (const d of drvs) { d.drv.dispose(); d.rt.dispose(); }
             }
         } finally {
