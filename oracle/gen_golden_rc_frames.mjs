@@ -65,6 +65,12 @@ async function main() {
             // clear the oldest item of a page (:283-297)
             { name: 'long_64x40', w: 64, h: 40, ratio: 2, frames: 16, seed: 27,
               from: k => [4 * Math.sin(0.9 * k), 1 + Math.cos(0.7 * k), 4 + 2 * Math.cos(0.9 * k)], to: k => [3 * Math.sin(1.3 * k), 0, -20] },
+            // Driver.cacheFactor (:32, read by createCache :245) set to 1 and to 0.5 between the constructor and prepare(): the cache
+            // is as large as the frame / half of it, pages are full and allocCacheItem clears and reuses their oldest item
+            { name: 'smallcache_64x40', w: 64, h: 40, ratio: 2, frames: 8, seed: 29, cacheFactor: 1,
+              from: k => [3 * Math.sin(0.8 * k), 1, 4 + Math.cos(0.8 * k)], to: k => [2 * Math.sin(1.1 * k), 0, -20] },
+            { name: 'halfcache_48x32', w: 48, h: 32, ratio: 1, frames: 5, seed: 30, cacheFactor: 0.5,
+              from: k => [0.8 * k, 0.5, 3], to: k => [-0.5 * k, 0, -20] },
             { name: 'onespp_odd_45x27', w: 45, h: 27, ratio: 2, frames: 4, seed: 28, method: 'nextFrame1SPP',
               from: k => [0.3 * k, 0.2 * k, 2.5], to: k => [0, 0.2 * k, -20] },
         ];
@@ -73,6 +79,7 @@ async function main() {
             const camera = new Camera(new Vector3(...cs.from(0)), new Vector3(...cs.to(0)), 30, cs.w, cs.h);
             const tracer = new Raytracer(scene, camera);
             const drv = new Driver(tracer, camera, cs.ratio);
+            if (cs.cacheFactor) drv.cacheFactor = cs.cacheFactor;
             drv.prepare(false);
             Math.random = makeRng(cs.seed);                     // after the constructors: three.js draws uuids from Math.random
             const rec = [], frames = new Uint32Array(2 * cs.w * cs.h * cs.frames);
@@ -95,7 +102,7 @@ async function main() {
             fs.writeFileSync(path.join(outDir, `frames_${cs.name}.u32`), Buffer.from(frames.buffer));
             index.cases[cs.name] = { file: `frames_${cs.name}.f64`, frames_file: `frames_${cs.name}.u32`, width: cs.w, height: cs.h,
                                      ratio: cs.ratio, frames: cs.frames, seed: cs.seed, fov: 30, doubles_per_frame: 67 + 7,
-                                     method: cs.method || 'nextFrame' };
+                                     method: cs.method || 'nextFrame', cache_factor: cs.cacheFactor || 4 };
         }
         fs.writeFileSync(path.join(outDir, 'frames_index.json'), JSON.stringify(index, null, 1));
     } finally {

@@ -338,6 +338,7 @@ async function gpuTests() {
                 const rt = new RayTracer(new Vector3(...desc.background), sceneFrom(desc), undefined, { mode: 'exact' });
                 const cam = new RcCamera(m.width, m.height);
                 const drv = new RenderCacheDriver(rt, cam, m.ratio, { resident });
+                drv.cacheFactor = m.cache_factor;                // (4 unless the case says otherwise: a plain field, as in the reference)
                 drv.prepare(false);
                 const px = m.width * m.height, got = new Uint32Array(px);
                 for (let k = 0; k < m.frames; k++) {

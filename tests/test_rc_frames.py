@@ -50,9 +50,9 @@ def dir_to_xy(x, y, w, h, proj_inv, world):
 class HostCache:
     """Driver.prepare + Driver.initializeCache (rendercache-js/src/Driver.js:81-88, :252-353) on flat arrays"""
 
-    def __init__(self, w, h, ratio):
+    def __init__(self, w, h, ratio, cache_factor=4):
         self.w, self.h, self.st = w, h, w + 2
-        cells, n = (w + 2) * (h + 2), w * h * 4
+        cells, n = (w + 2) * (h + 2), int(w * h * cache_factor)
         self.n = n
         self.max_samples = w * h * (1 / ratio)
         self.ratio = ratio
@@ -128,7 +128,7 @@ def test_golden_frames_are_complete(golden_dir):
         assert frames.shape[2] == m["width"] * m["height"], name
         assert np.isfinite(rec[:, 68:74]).all(), name
         n += m["frames"]
-    assert n == 34
+    assert n == 47
     n = 0
     for name, m, scene, rec, frames in frame_cases(golden_dir, "nextFrame1SPP"):
         assert frames.shape[2] == m["width"] * m["height"], name
@@ -146,7 +146,7 @@ def test_gpu_resident_frames_bit_exact(golden_dir):
             r.set_elements(scene["elements"])
             r.set_background(scene["background"])
             w, h = m["width"], m["height"]
-            host = HostCache(w, h, m["ratio"])
+            host = HostCache(w, h, m["ratio"], m["cache_factor"])
             v = rec[0]
             host.initialize(r, xorshift32(m["seed"]), v[0:3], v[3:19], v[51:67])
             r.rc_cache_create(w, h, host.n)
