@@ -71,6 +71,12 @@ async function main() {
               from: k => [3 * Math.sin(0.8 * k), 1, 4 + Math.cos(0.8 * k)], to: k => [2 * Math.sin(1.1 * k), 0, -20] },
             { name: 'halfcache_48x32', w: 48, h: 32, ratio: 1, frames: 5, seed: 30, cacheFactor: 0.5,
               from: k => [0.8 * k, 0.5, 3], to: k => [-0.5 * k, 0, -20] },
+            // the driver's tunables (plain fields, Driver.js:28-42) away from their defaults
+            { name: 'tuned_72x48', w: 72, h: 48, ratio: 4, frames: 6, seed: 31,
+              tunables: { ageFactor: 2, interpolationZero: 5, interpolationRandom: 1, priorityMax: 100, depthThreshold: 60 },
+              from: k => [1.5 * Math.sin(0.7 * k), 0.5 + 0.3 * k, 3], to: k => [0.6 * k, 0, -20] },
+            { name: 'tuned_50x50', w: 50, h: 50, ratio: 3, frames: 5, seed: 32, tunables: { ageFactor: 3, priorityMax: 7, interpolationZero: 60, interpolationRandom: 0 },
+              from: k => [-0.7 * k, 1, 2 + 0.5 * k], to: k => [0, 0.3 * k, -20] },
             { name: 'onespp_odd_45x27', w: 45, h: 27, ratio: 2, frames: 4, seed: 28, method: 'nextFrame1SPP',
               from: k => [0.3 * k, 0.2 * k, 2.5], to: k => [0, 0.2 * k, -20] },
         ];
@@ -81,6 +87,7 @@ async function main() {
             const drv = new Driver(tracer, camera, cs.ratio);
             if (cs.cacheFactor) drv.cacheFactor = cs.cacheFactor;
             drv.prepare(false);
+            Object.assign(drv, cs.tunables || {});
             Math.random = makeRng(cs.seed);                     // after the constructors: three.js draws uuids from Math.random
             const rec = [], frames = new Uint32Array(2 * cs.w * cs.h * cs.frames);
             for (let k = 0; k < cs.frames; k++) {
@@ -102,7 +109,9 @@ async function main() {
             fs.writeFileSync(path.join(outDir, `frames_${cs.name}.u32`), Buffer.from(frames.buffer));
             index.cases[cs.name] = { file: `frames_${cs.name}.f64`, frames_file: `frames_${cs.name}.u32`, width: cs.w, height: cs.h,
                                      ratio: cs.ratio, frames: cs.frames, seed: cs.seed, fov: 30, doubles_per_frame: 67 + 7,
-                                     method: cs.method || 'nextFrame', cache_factor: cs.cacheFactor || 4 };
+                                     method: cs.method || 'nextFrame', cache_factor: cs.cacheFactor || 4,
+                                     tunables: Object.assign({ ageFactor: 1, depthThreshold: 1e6, interpolationZero: 20, interpolationRandom: 5,
+                                                               priorityMax: 255 }, cs.tunables || {}) };
         }
         fs.writeFileSync(path.join(outDir, 'frames_index.json'), JSON.stringify(index, null, 1));
     } finally {

@@ -340,6 +340,7 @@ async function gpuTests() {
                 const drv = new RenderCacheDriver(rt, cam, m.ratio, { resident });
                 drv.cacheFactor = m.cache_factor;                // (4 unless the case says otherwise: a plain field, as in the reference)
                 drv.prepare(false);
+                Object.assign(drv, m.tunables);                  // (the defaults unless the case says otherwise)
                 const px = m.width * m.height, got = new Uint32Array(px);
                 for (let k = 0; k < m.frames; k++) {
                     const o = k * m.doubles_per_frame;

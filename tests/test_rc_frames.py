@@ -83,7 +83,7 @@ class HostCache:
         self.cache_pointer = stop
         return take
 
-    def initialize(self, renderer, rng, cam_from, world, proj_inv):     # initializeCache (:328-353)
+    def initialize(self, renderer, rng, cam_from, world, proj_inv, age_factor=1.0):     # initializeCache (:328-353)
         s = self.state
         usage = 0.0
         while usage < 0.2:
@@ -105,7 +105,7 @@ class HostCache:
                 s["item_hit"][3 * it:3 * it + 3] = hit[k]
                 s["pixel_rgb"][s["item_pixel"][it]] = s["item_rgb"][it]
             for it in requests:                                         # age(ageFactor, requests) (:936-942)
-                s["item_age"][it] += 1
+                s["item_age"][it] += age_factor
             usage += 1 / self.ratio
 
 
@@ -128,7 +128,7 @@ def test_golden_frames_are_complete(golden_dir):
         assert frames.shape[2] == m["width"] * m["height"], name
         assert np.isfinite(rec[:, 68:74]).all(), name
         n += m["frames"]
-    assert n == 47
+    assert n == 58
     n = 0
     for name, m, scene, rec, frames in frame_cases(golden_dir, "nextFrame1SPP"):
         assert frames.shape[2] == m["width"] * m["height"], name
@@ -148,12 +148,14 @@ def test_gpu_resident_frames_bit_exact(golden_dir):
             w, h = m["width"], m["height"]
             host = HostCache(w, h, m["ratio"], m["cache_factor"])
             v = rec[0]
-            host.initialize(r, xorshift32(m["seed"]), v[0:3], v[3:19], v[51:67])
+            t = m["tunables"]
+            host.initialize(r, xorshift32(m["seed"]), v[0:3], v[3:19], v[51:67], t["ageFactor"])
             r.rc_cache_create(w, h, host.n)
             r.rc_cache_upload(host.state, host.cache_pointer)
             for k in range(m["frames"]):
                 v = rec[k]
-                st = r.rc_next_frame(v[0:3], v[3:19], v[19:35], v[35:51], v[51:67], host.max_samples)
+                st = r.rc_next_frame(v[0:3], v[3:19], v[19:35], v[35:51], v[51:67], host.max_samples, t["ageFactor"], t["depthThreshold"],
+                                     t["interpolationZero"], t["interpolationRandom"], t["priorityMax"])
                 want = v[67:74]
                 tag = f"{name} frame {k}"
                 assert (np.isnan(st["threshold"]) and np.isnan(want[0])) or st["threshold"] == want[0], tag
