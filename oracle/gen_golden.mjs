@@ -185,7 +185,12 @@ async function main() {
 
         // ---- (2) sha256 + probe pixels of the big frames
         const bigs = [['example1', 640, 480], ['example1', 1920, 1080], ['example1', 3840, 2160],
-                      ['anim_t1234', 1920, 1080], ['random_5', 640, 480]];
+                      ['anim_t1234', 1920, 1080], ['random_5', 640, 480],
+                      // hashes alone of every other scene at sizes the small frames do not reach (odd ones among them)
+                      ...[0, 1, 2, 3, 4, 6, 7].map(s => ['random_' + s, 640, 480]),
+                      ['inside_sphere', 640, 480], ['odd_colours', 640, 480], ['coincident', 640, 480],
+                      ['light_below_horizon', 640, 480], ['occluder_behind_light', 640, 480], ['no_lights', 320, 240],
+                      ['example1_permuted', 800, 600], ['anim_t98765', 1280, 720], ['example1', 1001, 563], ['random_7', 1279, 719]];
         for (const [name, w, h] of bigs) {
             const buf = mkTracer(scenes[name]).render(w, h);
             const v = new Uint32Array(buf);

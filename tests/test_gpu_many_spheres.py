@@ -84,7 +84,9 @@ def test_forced_many_kernel_golden_frames(rdr2, golden_dir, golden_index, scenes
         assert bad.size == 0, f"{key}: {bad.size} pixels differ, first {bad[:5]}"
 
 
-@pytest.mark.parametrize("key", ["example1@1920x1080", "example1@3840x2160", "anim_t1234@1920x1080", "random_5@640x480"])
+@pytest.mark.parametrize("key", ["example1@1920x1080", "example1@3840x2160", "anim_t1234@1920x1080", "random_5@640x480",
+                                 "random_7@1279x719", "random_6@640x480", "inside_sphere@640x480", "coincident@640x480",
+                                 "example1@1001x563", "anim_t98765@1280x720"])
 def test_forced_many_kernel_big_hashes(rdr2, golden_index, scenes, key):
     import hashlib
     meta = golden_index["hashes"][key]

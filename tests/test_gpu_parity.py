@@ -76,6 +76,25 @@ def test_big_frame_hashes(rdr, golden_index, scenes, key, mode):
             assert st["reshaded"] > st["retraced"], st
 
 
+MORE_HASHES = ["random_0@640x480", "random_1@640x480", "random_2@640x480", "random_3@640x480", "random_4@640x480", "random_6@640x480",
+               "random_7@640x480", "inside_sphere@640x480", "odd_colours@640x480", "coincident@640x480", "light_below_horizon@640x480",
+               "occluder_behind_light@640x480", "no_lights@320x240", "example1_permuted@800x600", "anim_t98765@1280x720",
+               "example1@1001x563", "random_7@1279x719"]
+
+
+@pytest.mark.parametrize("mode", ["exact", "hybrid"])
+@pytest.mark.parametrize("key", MORE_HASHES)
+def test_more_reference_hashes(rdr, golden_index, scenes, key, mode):
+    """hashes alone of the other golden scenes at larger and odd sizes (the unmodified reference under Node, oracle/gen_golden.mjs)"""
+    meta = golden_index["hashes"][key]
+    _load(rdr, scenes[key.split("@")[0]])
+    w, h = meta["width"], meta["height"]
+    got = rdr.render(w, h, flags=Q | MODES[mode])
+    for x, y, v in meta["probes"]:
+        assert int(got[y * w + x]) == v, (x, y)
+    assert hashlib.sha256(got.tobytes()).hexdigest() == meta["sha256"]
+
+
 @pytest.mark.parametrize("mode", ["exact", "hybrid"])
 def test_banded_render(rdr, golden_dir, golden_index, scenes, mode):
     for key, meta in golden_index["bands"].items():

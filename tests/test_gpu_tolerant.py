@@ -81,6 +81,23 @@ def test_big_frames_against_the_float64_kernel(rdr, golden_index, scenes, key):
           f"{differ} of {w * h} px differ from the reference by one unit")
 
 
+def test_more_reference_scenes_within_one_unit(rdr, golden_index, scenes):
+    """every other frame whose hash the reference left (tests/test_gpu_parity.py pins the float64 kernel to it): larger and odd sizes"""
+    known = ("example1@640x480", "example1@1920x1080", "example1@3840x2160", "anim_t1234@1920x1080", "random_5@640x480")
+    seen = 0
+    for key, meta in golden_index["hashes"].items():
+        if key in known:
+            continue
+        _load(rdr, scenes[key.split("@")[0]])
+        w, h = meta["width"], meta["height"]
+        exact = rdr.render(w, h, flags=Q | ptr_amd.MODE_EXACT_F64)
+        got = rdr.render(w, h, flags=Q | TOL)
+        assert _max_channel_diff(got, exact) <= 1, key             # tolerance: 1/255 per channel, every pixel
+        assert np.array_equal(got >> 24, exact >> 24), key
+        seen += 1
+    assert seen == 17
+
+
 def test_unshifted_and_float32_outputs(rdr, scenes):
     sc = scenes["example1"]
     _load(rdr, sc)

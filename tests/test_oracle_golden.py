@@ -44,6 +44,24 @@ def test_big_frame_hashes(golden_index, scenes, key):
     assert not got[(h - 1) * w:].any()
 
 
+MORE_HASHES = ["random_0@640x480", "random_1@640x480", "random_2@640x480", "random_3@640x480", "random_4@640x480", "random_6@640x480",
+               "random_7@640x480", "inside_sphere@640x480", "odd_colours@640x480", "coincident@640x480", "light_below_horizon@640x480",
+               "occluder_behind_light@640x480", "no_lights@320x240", "example1_permuted@800x600", "anim_t98765@1280x720",
+               "example1@1001x563", "random_7@1279x719"]
+
+
+@pytest.mark.parametrize("key", MORE_HASHES)
+def test_more_reference_hashes(golden_index, scenes, key):
+    """hashes alone of the other golden scenes at larger and odd sizes (the unmodified reference under Node, oracle/gen_golden.mjs)"""
+    meta = golden_index["hashes"][key]
+    sc = scenes[key.split("@")[0]]
+    w, h = meta["width"], meta["height"]
+    got = orc.render(orc.scene_to_soa(sc["elements"]), sc["background"], w, h, threads=8)
+    assert hashlib.sha256(got.tobytes()).hexdigest() == meta["sha256"]
+    for x, y, v in meta["probes"]:
+        assert int(got[y * w + x]) == v
+
+
 def test_survey_anchor_hashes(golden_index):
     # SURVEY.md §7 step 1 anchors, measured by the survey session on the unmodified reference
     assert golden_index["hashes"]["example1@640x480"]["sha256"] == \
