@@ -52,6 +52,10 @@ async function main() {
             { name: 'move_96x64', w: 96, h: 64, fromA: [0, 0, 0], toA: [0, 0, -20], fromB: [1.5, 0.8, 2.0], toB: [0.5, 0, -20], seed: 11 },
             { name: 'turn_64x48', w: 64, h: 48, fromA: [0, 2, 5], toA: [0, 0, -20], fromB: [6, 3, 0], toB: [-3, 0, -22], seed: 12 },
             { name: 'same_48x32', w: 48, h: 32, fromA: [0, 0, 0], toA: [0, 0, -20], fromB: [0, 0, 0], toB: [0, 0, -20], seed: 13 },
+            // odd sizes and the driver's tunables (plain fields, Driver.js:28-42) away from their defaults: a depth threshold that
+            // rejects the far hits, an age factor that is no integer
+            { name: 'tuned_45x27', w: 45, h: 27, fromA: [0, 1, 2], toA: [0, 0, -20], fromB: [2, 0.5, 4], toB: [-1, 0, -20], seed: 14,
+              tunables: { ageFactor: 2.5, depthThreshold: 40, interpolationZero: 5, interpolationRandom: 1, priorityMax: 100 } },
         ];
         for (const cs of cases) {
             const rng = makeRng(cs.seed);
@@ -60,6 +64,7 @@ async function main() {
             const tracer = new Raytracer(scene, camera);
             const drv = new Driver(tracer, camera, 16);
             drv.prepare(false);
+            Object.assign(drv, cs.tunables || {});
             camera.updatePosition(new Vector3(...cs.fromA), new Vector3(...cs.toA));
             camera.cam.updateMatrixWorld();                    // camera A as the page would have it after a frame
             // fill about 70 % of the cache with hits traced through random pixels of camera A

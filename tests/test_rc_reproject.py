@@ -45,12 +45,12 @@ def test_oracle_reproduces_the_reference_pass(golden_dir):
                                c["age_factor"], c["depth_threshold"])
         check(name, c, *out)
         # the fixture exercises every branch: no hit, depth 0 (+4), outside (+2), loser (+1), displaced winner, winner
-        d = c["age_out"] - c["age_in"]
+        d = (c["age_out"] - c["age_in"]) / c["age_factor"]
         assert set(np.unique(d)) >= ({0.0, 1.0, 4.0} if name.startswith("same") else {0.0, 1.0, 2.0, 4.0}), name
         displaced = (c["item_pixel"] >= 0) & (c["pixel_element"][np.maximum(c["item_pixel"], 0)] != np.arange(c["items"]))
         assert displaced.any(), name
         seen += 1
-    assert seen == 3
+    assert seen == 4
 
 
 @pytest.mark.gpu
