@@ -298,6 +298,11 @@ export default class RenderCacheDriver {
             }
         }
         this.statistics.candidates = candPixel.length;
+        // (no sample counted at any level up to priorityMax: the reference's loop below adds 0 to `index` for ever; refused here
+        // as the resident form refuses it, ptr_rc_next_frame)
+        if (candPixel.length > 0 && (!(requestFactor > 0) || candPixel.length / requestFactor > 4.0e9))
+            throw new RangeError(`request factor ${requestFactor} with ${candPixel.length} candidates: the reference's pick loop ` +
+                                 '(Driver.js:795-822) would not end');
 
         const requests = [];
         let index = 0, lastI = null;

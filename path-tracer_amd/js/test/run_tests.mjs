@@ -625,6 +625,17 @@ async function gpuTests() {
         assert.strictEqual(sha(a), sha(b));
         assert.ok(/rays requested/.test(a));
     });
+    test('RenderCacheDriver: random set-ups of the frame loop, resident against host walks (test/soak_rc_loop.mjs, a short run); a frame with no sample counted is refused by both', () => {
+        const run = (...a) => {
+            const r = spawnSync(process.execPath, [path.join(here, 'soak_rc_loop.mjs'), ...a], { encoding: 'utf8', timeout: 120000 });
+            assert.strictEqual(r.status, 0, `soak_rc_loop ${a.join(' ')}: ${r.stderr}${r.stdout}`);
+            return r.stdout;
+        };
+        assert.ok(/40 set-ups, \d+ frames .* equal after every frame/.test(run('40', '7')));
+        // set-up 121 of seed 2 (130 x 18, priorityMax 7): its frame 7 counts no sample at any level - the reference's pick loop
+        // (Driver.js:795-825) adds 0 to its index for ever; the host walk and ptr_rc_next_frame both refuse the frame instead
+        assert.ok(/ 1 set-ups ended by a frame that both forms refuse/.test(run('122', '2', '121')));
+    });
     test('renderInto(): the frame in the caller\'s own buffer equals render()\'s; wrong targets are refused', () => {
         const rt = new RayTracer(new Vector3(2, 2, 2), buildExample1());
         const want = new Uint8Array(rt.render(160, 120));
