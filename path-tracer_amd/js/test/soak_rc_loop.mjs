@@ -9,7 +9,7 @@ import { Vector3, Material, Sphere, Scene, RayTracer, RenderCacheDriver, RcCamer
 import { perspectiveView } from '../examples/common.js';
 
 const trials = Number(process.argv[2] || 100), seed0 = Number(process.argv[3] || 1), first = Number(process.argv[4] || 0);
-const verbose = !!process.env.PTR_SOAK_VERBOSE;
+const verbose = !!process.env.PTR_SOAK_VERBOSE, scale = Number(process.env.PTR_SOAK_SCALE || 1);      // PTR_SOAK_SCALE=8: frames up to 2 464 x 832
 
 function mulberry(seed) {
     let a = seed >>> 0;
@@ -36,7 +36,8 @@ const t0 = Date.now();
 for (let t = first; t < trials; t++) {
     const r = mulberry(seed0 * 100003 + t);
     const pick = a => a[Math.floor(r() * a.length)];
-    const w = r() < 0.1 ? 8 + Math.floor(r() * 300) : 8 + Math.floor(r() * 140), h = r() < 0.05 ? 1 + Math.floor(r() * 3) : 4 + Math.floor(r() * 100);
+    const w = scale * (r() < 0.1 ? 8 + Math.floor(r() * 300) : 8 + Math.floor(r() * 140)) + (scale > 1 ? Math.floor(r() * scale) : 0);
+    const h = r() < 0.05 ? 1 + Math.floor(r() * 3) : scale * (4 + Math.floor(r() * 100)) + (scale > 1 ? Math.floor(r() * scale) : 0);
     const ratio = pick([1, 2, 3, 4, 8, 16, 32]), nframes = 3 + Math.floor(r() * 6);
     const before = r() < 0.35 ? { cacheFactor: pick([0.5, 1, 1.5, 2]) } : {};
     if (before.cacheFactor && !Number.isInteger(w * h * before.cacheFactor)) before.cacheFactor = Math.ceil(before.cacheFactor);
@@ -97,7 +98,7 @@ for (let t = first; t < trials; t++) {
     }
     reusedAll += reused;
     for (const d of drvs) { d.drv.dispose(); d.rt.dispose(); }
-    if ((t + 1) % 20 === 0) console.log(`  ${t + 1} trials, ${frames} frames, ${((Date.now() - t0) / 1000).toFixed(0)} s`);
+    if ((t + 1) % (scale > 1 ? 2 : 20) === 0) console.log(`  ${t + 1} trials, ${frames} frames, ${((Date.now() - t0) / 1000).toFixed(0)} s`);
 }
 console.log(`soak_rc_loop seed ${seed0}: ${trials} set-ups, ${frames} frames = ${(pixels / 1e6).toFixed(1)} M pixels, ${reusedAll} items reused from full pages, ` +
             `${refused} set-ups ended by a frame that both forms refuse (no sample counted: the reference's pick loop would not end); ` +
